@@ -1,0 +1,220 @@
+/*
+ * mfcc_amd -- MI355X (gfx950) feature extraction behind the reference's C-style interface.
+ *
+ * Plain C ABI: pointers, sizes and int status codes only.  Every function returns 0 on success
+ * or a negative MFCC_E_* code; MFCCLastError() gives the message of the calling thread's last
+ * failure.  Nothing here exits the process or waits for a key press (the reference's error path,
+ * main.c:130-139,182,192-196,218-222,273, does both).
+ *
+ * The product never computes features on the CPU: every extraction entry point needs a HIP
+ * device and fails with MFCC_E_DEVICE when none is usable.
+ */
+#ifndef MFCC_AMD_H
+#define MFCC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFCC_MAX_PATH 600 /* maxBuffLength, main.c:13: line buffer of the list and of fileList */
+
+enum {
+    MFCC_OK = 0,
+    MFCC_E_INI_OPEN = -1,    /* main.c:130-134 "Can't load '.ini'" */
+    MFCC_E_INI_KEY = -2,     /* main.c:135-139 unknown key / malformed line */
+    MFCC_E_OPEN = -3,        /* main.c:182 "open .wav failed", main.c:160 list open */
+    MFCC_E_WAV = -4,         /* malformed or unsupported RIFF/WAVE */
+    MFCC_E_SAMPLE_RATE = -5, /* main.c:192-196 "Sample rate not right" */
+    MFCC_E_VECNUM = -6,      /* main.c:218-222 vecNum > rows derived from the channels */
+    MFCC_E_WRITE = -7,       /* main.c:273 "open result.dat failed" */
+    MFCC_E_CONFIG = -8,      /* option out of range for the kernels (sizes, flags) */
+    MFCC_E_DEVICE = -9,      /* no usable HIP device / HIP runtime error */
+    MFCC_E_ARG = -10,        /* NULL or inconsistent argument */
+    MFCC_E_NOMEM = -11
+};
+
+enum { MFCC_SAVE_F = 0, MFCC_SAVE_E = 1, MFCC_SAVE_N = 2, MFCC_SAVE_B = 3 };
+enum { MFCC_PREC_F32 = 0, MFCC_PREC_F64 = 1 };
+
+/*
+ * Option set.  Replaces `Config` (main.c:41-65) and carries the README-only keys
+ * zeroMeanSigFlag (README.md:88), znormFlag (README.md:122), numThreads (README.md:134) and the
+ * saveType values n / b (README.md:133).  `precision` has no counterpart in the reference (which
+ * is double throughout): it selects the arithmetic type of the HIP kernels.
+ */
+typedef struct MFCCConfig {
+    int sampleRate;
+    double hipassfre;
+    double lowpassfre;
+    double preemphasise;
+    int wlen;
+    int inc;
+    int vecNum;
+    int fbankFlag;
+    int bankNum;
+    int MFCCNum;
+    int MFCC0thFlag;
+    int energyFlag;
+    int zeroCrossingFlag;
+    int brightFlag;
+    int subBandEFlag; /* a count, not a flag (main.c:163,246) */
+    int fftLength;
+    int regreOrder;
+    int delwin;
+    int zeroMeanSigFlag;
+    int znormFlag;
+    int saveType;   /* MFCC_SAVE_* ; ini letters f / e / n / b (main.c:76-80, README.md:133) */
+    int numThreads; /* host threads used by MFCCWapperList for file reading and writing */
+    int precision;  /* MFCC_PREC_* */
+    char fileList[MFCC_MAX_PATH];
+} MFCCConfig;
+
+/* Thread-local message of the last failed call ("" if none). */
+const char *MFCCLastError(void);
+
+/* Releases any buffer this library handed out (feature matrices). */
+void MFCCFree(void *p);
+
+/* Fills *cfg with neutral defaults (all flags 0, regreOrder 1, numThreads 1, f32). */
+int MFCCConfigDefaults(MFCCConfig *cfg);
+
+/*
+ * Reads config.ini.  Replaces ini_parse + handler (main.c:67-96,129).  Accepts the snapshot's
+ * layout and the README's: saveType / fileList in [Frame] or [IO], trailing " ;" comments, section
+ * lines ending "];".  Keys of the snapshot that are missing stay at their defaults.  Returns
+ * MFCC_E_INI_OPEN, or MFCC_E_INI_KEY with *badLine (may be NULL) set to the first offending line.
+ * Applies main.c:141-144: fbankFlag forces MFCCNum = bankNum and MFCC0thFlag = 0.
+ */
+int MFCCConfigFromIni(const char *iniPath, MFCCConfig *cfg, int *badLine);
+
+/* Frame count of main.c:211 (C integer division), 0 when the file is shorter than one window. */
+long MFCCNumFrames(long numSamples, int wlen, int inc);
+/* Per-vec feature width (main.c:161 + MFCCNum) and row width `step` (main.c:254). */
+int MFCCFeatureDim(const MFCCConfig *cfg);
+int MFCCStep(const MFCCConfig *cfg);
+
+/*
+ * Per-file entry point.  Replaces the body of the list loop, main.c:178-289, which the README
+ * (README.md:142) calls MFCCWapper.  Reads wavPath, extracts on the current HIP device and
+ *   - writes outPath in cfg->saveType layout when outPath != NULL,
+ *   - returns the [numFrames x step] row-major matrix in *features when features != NULL
+ *     (release with MFCCFree).
+ */
+int MFCCWapper(const MFCCConfig *cfg, const char *wavPath, const char *outPath, double **features,
+               long *numFrames, int *step);
+
+/* Same as MFCCWapper on a WAV file image already in memory. */
+int MFCCWapperMem(const MFCCConfig *cfg, const void *wavFile, size_t wavLen, const char *outPath,
+                  double **features, long *numFrames, int *step);
+
+/*
+ * Whole-run entry point.  Replaces main() (main.c:98-300): reads the ini, then every
+ * "src<TAB>dst" line of cfg.fileList until the first blank line (main.c:173-177).  A file that
+ * fails is reported and skipped; the return value is the number of failed files (0 = all good)
+ * or a negative code when the ini or the list cannot be read.  Files are batched onto the GPU.
+ */
+int MFCCWapperList(const char *iniPath);
+
+/* Output layouts of main.c:272-287 (f, e) and cnpy.hpp:88-131,235-264 (n); b = raw little-endian
+ * doubles, row-major, no header. */
+int MFCCWriteFeatures(const char *path, const double *data, long numFrames, int step, int saveType);
+
+/* RIFF/WAVE header walk (README.md:68; replaces loadWAVEFile, main.c:190-191). */
+int MFCCWavInfo(const void *wavFile, size_t wavLen, int *channels, int *sampleRate,
+                int *bytesPerSample, long *numSamples, size_t *dataOffset);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-resident batched path: PCM bytes already in HBM, features left in HBM.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct MFCCContext MFCCContext; /* tables + device for one option set */
+typedef struct MFCCPlan MFCCPlan;       /* one batch: utterance table, tiles, scratch */
+
+/* Builds the host tables (InitFBank mfcc.c:39-122, GenHamWindow main.c:171, the DCT matrix of
+ * mfcc.c:186-193) in double and uploads them to `device`. */
+int MFCCContextCreate(const MFCCConfig *cfg, int device, MFCCContext **ctx);
+void MFCCContextDestroy(MFCCContext *ctx);
+/* The two lines InitFBank prints (mfcc.c:74-75), formatted into buf. */
+int MFCCContextPassbandText(const MFCCContext *ctx, char *buf, size_t cap);
+/* Copies the filterbank tables out (any pointer may be NULL): cf[bankNum+1], loChan[fftN/2],
+ * loWt[fftN/2] with entry [k-1] holding the reference's 1-based [k]. */
+int MFCCContextTables(const MFCCContext *ctx, int *fftN, int *klo, int *khi, double *cf,
+                      int *loChan, double *loWt);
+
+/*
+ * Plans a batch of nUtts independent utterances that share one packed PCM buffer of interleaved
+ * little-endian samples: utterance u starts byteOff[u] bytes into the buffer and has
+ * numSamples[u] sample instants of `channels` x `bytesPerSample` bytes.  Its feature rows start
+ * at row MFCCPlanRowOffset(plan, u) of the output matrix; rows are `step` wide.
+ */
+int MFCCPlanCreate(MFCCContext *ctx, int channels, int bytesPerSample, int nUtts,
+                   const int64_t *byteOff, const int64_t *numSamples, MFCCPlan **plan);
+
+/*
+ * Plans frames [frameBegin, frameEnd) of ONE recording of totalSamples instants for a rank that
+ * holds only part of it.  The rank must supply the PCM bytes of instants
+ * [MFCCPlanSampleBegin, MFCCPlanSampleBegin + MFCCPlanSampleCount): its frames, the delta halo
+ * of (regreOrder-1)*delwin frames on each interior side and one lead instant for pre-emphasis.
+ * The output matrix holds MFCCPlanTotalRows rows; the rank's own frames start at row
+ * MFCCPlanOwnedRowBegin.  chanSum2 (may be NULL unless zeroMeanSigFlag): twice the integer sum of
+ * every derived row {L, R, mid, side} over the WHOLE recording, used for the zero-mean option.
+ */
+int MFCCPlanCreateShard(MFCCContext *ctx, int channels, int bytesPerSample, int64_t totalSamples,
+                        int64_t frameBegin, int64_t frameEnd, const int64_t *chanSum2,
+                        MFCCPlan **plan);
+void MFCCPlanDestroy(MFCCPlan *plan);
+
+int64_t MFCCPlanTotalRows(const MFCCPlan *plan);
+int64_t MFCCPlanRowOffset(const MFCCPlan *plan, int utt);
+int64_t MFCCPlanNumFrames(const MFCCPlan *plan, int utt);
+int64_t MFCCPlanSampleBegin(const MFCCPlan *plan);
+int64_t MFCCPlanSampleCount(const MFCCPlan *plan);
+int64_t MFCCPlanOwnedRowBegin(const MFCCPlan *plan);
+int64_t MFCCPlanOwnedRows(const MFCCPlan *plan);
+
+/*
+ * Runs the planned batch on `stream` (a hipStream_t, NULL = default stream), asynchronously:
+ * static features -> regression deltas -> (batch plans only) per-utterance z-norm.
+ * pcmDev: device pointer to the packed PCM bytes (pcmBytes of them are readable).
+ * outDev: device matrix [MFCCPlanTotalRows x step] of float (MFCC_PREC_F32) or double.
+ * No allocation and no host synchronisation happens here except when zeroMeanSigFlag is set on a
+ * batch plan (the row means are then reduced on the device first, still asynchronously).
+ */
+int MFCCExtractDevice(MFCCContext *ctx, MFCCPlan *plan, const void *pcmDev, size_t pcmBytes,
+                      void *outDev, void *stream);
+
+/* Shard plans: z-norm is split so the caller can all-reduce the statistics between the two.
+ * MFCCShardColumnSums writes 2*step+1 doubles to sumsDev: sum x, sum x^2 per column over the
+ * rank's own rows, then the row count.  MFCCShardNormalize applies (x - mean) / std given the
+ * all-reduced vector of the same layout. */
+int MFCCShardColumnSums(MFCCContext *ctx, MFCCPlan *plan, const void *outDev, double *sumsDev,
+                        void *stream);
+int MFCCShardNormalize(MFCCContext *ctx, MFCCPlan *plan, void *outDev, const double *sumsDev,
+                       void *stream);
+/* Twice the integer sum of each derived row {L, R, mid, side} over instants
+ * [sampleBegin, sampleBegin + count) of the bytes at pcmDev (instant 0 = first byte): 4 int64
+ * written to sums2Dev.  Ranks add these up to feed MFCCPlanCreateShard's chanSum2. */
+int MFCCChannelSums(MFCCContext *ctx, const void *pcmDev, int channels, int bytesPerSample,
+                    int64_t sampleBegin, int64_t count, int64_t *sums2Dev, void *stream);
+
+/* Elapsed milliseconds the dominant (static feature) kernel took in the most recent
+ * MFCCExtractDevice on this plan, measured with HIP events on the launch stream; synchronises
+ * on the stop event.  Negative when timing was not enabled with MFCCPlanEnableTiming. */
+int MFCCPlanEnableTiming(MFCCPlan *plan, int on);
+float MFCCPlanLastKernelMs(MFCCPlan *plan);
+
+/* Deterministic synthetic PCM used by the benchmark and the tests (integer-only generator, so the
+ * bytes are identical on every machine): triangular-pdf noise from a 64-bit LCG seeded with
+ * `seed`, optional integer-table tone of `toneHz` at -12 dBFS added; 16- or 24-bit samples.
+ * Host code; writes numSamples * bytesPerSample bytes (one channel) to dst with stride
+ * channels * bytesPerSample starting at channel `ch`. */
+int MFCCSynthPcm(void *dst, int channels, int ch, int bytesPerSample, int64_t numSamples,
+                 uint64_t seed, int sampleRate, int toneHz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,881 @@
+// C ABI: contexts, batch / shard plans, device extraction, and the reference-shaped entry points
+// MFCCWapper (per file, main.c:178-289) and MFCCWapperList (whole run, main.c:98-300).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mfcc_host.h"
+
+using namespace mfcc;
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_error("HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), __FILE__, \
+                      __LINE__);                                                            \
+            return MFCC_E_DEVICE;                                                           \
+        }                                                                                   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+
+struct MFCCContext {
+    MFCCConfig cfg;
+    Tables tab;
+    int device = 0;
+    int M = 0, c0 = 0, D = 0, vSize = 0, step = 0;
+    void *dWindow = nullptr, *dTw = nullptr, *dSplitTw = nullptr, *dLoWt = nullptr, *dDct = nullptr;
+    int32_t *dChanRange = nullptr;
+};
+
+struct MFCCPlan {
+    MFCCContext *ctx = nullptr;
+    bool shard = false;
+    int channels = 0, bps = 0, numUtts = 0;
+    std::vector<UttDesc> utts;
+    int64_t totalRows = 0;
+    int numTiles = 0, numChunks = 0;
+    int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0;
+    size_t ldsBytes = 0;
+    UttDesc *dUtts = nullptr;
+    int32_t *dTileUtt = nullptr, *dChunkUtt = nullptr;
+    double *dPartial = nullptr, *dStats = nullptr;
+    unsigned long long *dSums2 = nullptr;
+    int64_t sampleBegin = 0, sampleCount = 0, ownedRowBegin = 0, ownedRows = 0;
+    bool timing = false, timed = false;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+};
+
+template <typename T>
+static int upload(const std::vector<double> &src, void **dst)
+{
+    std::vector<T> tmp(src.size());
+    for (size_t i = 0; i < src.size(); ++i) tmp[i] = (T)src[i];
+    const size_t bytes = std::max<size_t>(tmp.size() * sizeof(T), 16);
+    HIP_TRY(hipMalloc(dst, bytes));
+    if (!tmp.empty()) HIP_TRY(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MFCC_OK;
+}
+
+static int upload_tab(int precision, const std::vector<double> &src, void **dst)
+{
+    return precision == MFCC_PREC_F64 ? upload<double>(src, dst) : upload<float>(src, dst);
+}
+
+extern "C" int MFCCContextCreate(const MFCCConfig *cfgIn, int device, MFCCContext **out)
+{
+    if (!cfgIn || !out) return set_error("NULL argument"), MFCC_E_ARG;
+    *out = nullptr;
+    MFCCConfig cfg = *cfgIn;
+    if (cfg.fbankFlag) { /* main.c:142-144 */
+        cfg.MFCCNum = cfg.bankNum;
+        cfg.MFCC0thFlag = 0;
+    }
+    int rc = validate_config(cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_error("no HIP device available (the library has no CPU path)"), MFCC_E_DEVICE;
+    if (device < 0 || device >= ndev) return set_error("device %d out of range", device), MFCC_E_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<MFCCContext> c(new MFCCContext);
+    c->cfg = cfg;
+    c->device = device;
+    rc = build_tables(cfg, c->tab);
+    if (rc) return rc;
+    if (c->tab.log2nc < 1 || c->tab.log2nc > kMaxLog2Nc)
+        return set_error("fftN %d is outside the supported range", c->tab.fftN), MFCC_E_CONFIG;
+    c->M = eff_mfccnum(cfg);
+    c->c0 = eff_c0(cfg);
+    c->D = MFCCFeatureDim(&cfg);
+    c->vSize = c->D * cfg.vecNum;
+    c->step = c->vSize * cfg.regreOrder;
+    const int p = cfg.precision;
+    if ((rc = upload_tab(p, c->tab.window, &c->dWindow))) return rc;
+    if ((rc = upload_tab(p, c->tab.tw, &c->dTw))) return rc;
+    if ((rc = upload_tab(p, c->tab.splitTw, &c->dSplitTw))) return rc;
+    if ((rc = upload_tab(p, c->tab.loWt, &c->dLoWt))) return rc;
+    if ((rc = upload_tab(p, c->tab.dct, &c->dDct))) return rc;
+    HIP_TRY(hipMalloc((void **)&c->dChanRange, c->tab.chanRange.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(c->dChanRange, c->tab.chanRange.data(),
+                      c->tab.chanRange.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    *out = c.release();
+    return MFCC_OK;
+}
+
+extern "C" void MFCCContextDestroy(MFCCContext *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->dWindow);
+    (void)hipFree(c->dTw);
+    (void)hipFree(c->dSplitTw);
+    (void)hipFree(c->dLoWt);
+    (void)hipFree(c->dDct);
+    (void)hipFree(c->dChanRange);
+    delete c;
+}
+
+extern "C" int MFCCContextPassbandText(const MFCCContext *c, char *buf, size_t cap)
+{
+    if (!c || !buf) return set_error("NULL argument"), MFCC_E_ARG;
+    snprintf(buf, cap, "FFT passband %d to %d out of 1 to %d\nMel passband %f to %f\n", c->tab.klo,
+             c->tab.khi, c->tab.nc, c->tab.mlo, c->tab.mhi); /* mfcc.c:74-75 */
+    return MFCC_OK;
+}
+
+extern "C" int MFCCContextTables(const MFCCContext *c, int *fftN, int *klo, int *khi, double *cf,
+                                 int *loChan, double *loWt)
+{
+    if (!c) return set_error("NULL argument"), MFCC_E_ARG;
+    if (fftN) *fftN = c->tab.fftN;
+    if (klo) *klo = c->tab.klo;
+    if (khi) *khi = c->tab.khi;
+    if (cf) std::copy(c->tab.cf.begin(), c->tab.cf.end(), cf);
+    if (loChan) std::copy(c->tab.loChan.begin(), c->tab.loChan.end(), loChan);
+    if (loWt) std::copy(c->tab.loWt.begin(), c->tab.loWt.end(), loWt);
+    return MFCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// plans
+// ------------------------------------------------------------------------------------------
+
+static int choose_tile(MFCCPlan *p)
+{
+    const MFCCContext *c = p->ctx;
+    const int V = c->cfg.vecNum, log2nc = c->tab.log2nc, prec = c->cfg.precision;
+    const int groups = front_groups(log2nc), zPitch = front_zpitch(log2nc);
+    const size_t el = prec == MFCC_PREC_F64 ? 8 : 4;
+    const int bpi = p->channels * p->bps;
+    const int base = (groups + V - 1) / V;
+    auto geometry = [&](int ft, int &rowPitch, int &rawOrZ) {
+        const long ninst = (long)(ft - 1) * c->cfg.inc + c->cfg.wlen + 1;
+        rowPitch = (int)((ninst + 3) & ~3L);
+        const size_t rawBytes = (size_t)ninst * bpi + 48;
+        const size_t zElems = (size_t)groups * zPitch;
+        size_t n = std::max(zElems, (rawBytes + el - 1) / el);
+        n = (n + 3) & ~(size_t)3;
+        rawOrZ = (int)n;
+        return front_lds_bytes(prec, log2nc, V, rowPitch, zPitch, rawOrZ, ft, c->vSize, c->cfg.bankNum);
+    };
+    const size_t kPreferred = 64 * 1024, kMax = 160 * 1024;
+    int best = 0;
+    for (int m = 4; m >= 1 && !best; --m) {
+        int rp, rz;
+        if (geometry(base * m, rp, rz) <= kPreferred) best = base * m;
+    }
+    for (int ft = base; ft >= 1 && !best; --ft) {
+        int rp, rz;
+        if (geometry(ft, rp, rz) <= kMax) best = ft;
+    }
+    if (!best)
+        return set_error("wlen %d / fftN %d needs more than 160 KiB of LDS per workgroup",
+                         c->cfg.wlen, c->tab.fftN),
+               MFCC_E_CONFIG;
+    p->framesPerTile = best;
+    p->ldsBytes = geometry(best, p->rowPitch, p->rawOrZElems);
+    return MFCC_OK;
+}
+
+static int finish_plan(MFCCPlan *p)
+{
+    MFCCContext *c = p->ctx;
+    int rc = choose_tile(p);
+    if (rc) return rc;
+    std::vector<int32_t> tileUtt, chunkUtt;
+    int64_t tiles = 0, chunks = 0;
+    for (int u = 0; u < p->numUtts; ++u) {
+        UttDesc &d = p->utts[u];
+        const int nt = (d.numFrames + p->framesPerTile - 1) / p->framesPerTile;
+        const int ncb = (d.ownCount + kStatRows - 1) / kStatRows;
+        if (tiles + nt > 0x7fffffffLL || chunks + ncb > 0x7fffffffLL)
+            return set_error("batch too large: more than 2^31 tiles"), MFCC_E_ARG;
+        d.tileBegin = (int32_t)tiles;
+        d.statBegin = (int32_t)chunks;
+        tiles += nt;
+        chunks += ncb;
+    }
+    tileUtt.reserve((size_t)tiles);
+    chunkUtt.reserve((size_t)chunks);
+    for (int u = 0; u < p->numUtts; ++u) {
+        const UttDesc &d = p->utts[u];
+        tileUtt.insert(tileUtt.end(), (size_t)((d.numFrames + p->framesPerTile - 1) / p->framesPerTile), u);
+        chunkUtt.insert(chunkUtt.end(), (size_t)((d.ownCount + kStatRows - 1) / kStatRows), u);
+    }
+    p->numTiles = (int)tiles;
+    p->numChunks = (int)chunks;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t nu = std::max<size_t>(p->utts.size(), 1);
+    HIP_TRY(hipMalloc((void **)&p->dUtts, nu * sizeof(UttDesc)));
+    if (!p->utts.empty())
+        HIP_TRY(hipMemcpy(p->dUtts, p->utts.data(), p->utts.size() * sizeof(UttDesc), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&p->dTileUtt, std::max<size_t>(tileUtt.size(), 1) * sizeof(int32_t)));
+    if (!tileUtt.empty())
+        HIP_TRY(hipMemcpy(p->dTileUtt, tileUtt.data(), tileUtt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    const bool needStats = c->cfg.znormFlag != 0;
+    if (needStats) {
+        HIP_TRY(hipMalloc((void **)&p->dChunkUtt, std::max<size_t>(chunkUtt.size(), 1) * sizeof(int32_t)));
+        if (!chunkUtt.empty())
+            HIP_TRY(hipMemcpy(p->dChunkUtt, chunkUtt.data(), chunkUtt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&p->dPartial, std::max<size_t>(chunkUtt.size(), 1) * 2 * c->step * sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&p->dStats, nu * 2 * c->step * sizeof(double)));
+    }
+    if (c->cfg.zeroMeanSigFlag && !p->shard)
+        HIP_TRY(hipMalloc((void **)&p->dSums2, nu * 4 * sizeof(unsigned long long)));
+    return MFCC_OK;
+}
+
+extern "C" int MFCCPlanCreate(MFCCContext *c, int channels, int bytesPerSample, int nUtts,
+                              const int64_t *byteOff, const int64_t *numSamples, MFCCPlan **out)
+{
+    if (!c || !out || nUtts < 0 || (nUtts > 0 && (!byteOff || !numSamples)))
+        return set_error("bad argument to MFCCPlanCreate"), MFCC_E_ARG;
+    *out = nullptr;
+    if (channels < 1 || channels > 2 || bytesPerSample < 2 || bytesPerSample > 4)
+        return set_error("unsupported PCM layout: %d channels x %d bytes", channels, bytesPerSample), MFCC_E_WAV;
+    const int rows = channels == 2 ? 4 : channels; /* main.c:198-199 */
+    if (c->cfg.vecNum > rows)
+        return set_error("vecnum %d > num_channels %d", c->cfg.vecNum, channels), MFCC_E_VECNUM; /* main.c:218-222 */
+    std::unique_ptr<MFCCPlan> p(new MFCCPlan);
+    p->ctx = c;
+    p->channels = channels;
+    p->bps = bytesPerSample;
+    p->numUtts = nUtts;
+    p->utts.resize((size_t)nUtts);
+    int64_t row = 0;
+    for (int u = 0; u < nUtts; ++u) {
+        if (numSamples[u] < 0 || numSamples[u] > 0x7fffffffLL || byteOff[u] < 0)
+            return set_error("utterance %d: bad offset or length", u), MFCC_E_ARG;
+        UttDesc &d = p->utts[u];
+        memset(&d, 0, sizeof d);
+        d.byteOff = byteOff[u];
+        d.outRow = row;
+        d.numInstants = (int32_t)numSamples[u];
+        d.numFrames = (int32_t)MFCCNumFrames((long)numSamples[u], c->cfg.wlen, c->cfg.inc);
+        d.ownBegin = 0;
+        d.ownCount = d.numFrames;
+        row += d.numFrames;
+    }
+    p->totalRows = row;
+    p->ownedRows = row;
+    int rc = finish_plan(p.get());
+    if (rc) {
+        MFCCPlanDestroy(p.release());
+        return rc;
+    }
+    *out = p.release();
+    return MFCC_OK;
+}
+
+extern "C" int MFCCPlanCreateShard(MFCCContext *c, int channels, int bytesPerSample,
+                                   int64_t totalSamples, int64_t frameBegin, int64_t frameEnd,
+                                   const int64_t *chanSum2, MFCCPlan **out)
+{
+    if (!c || !out || totalSamples < 0) return set_error("bad argument to MFCCPlanCreateShard"), MFCC_E_ARG;
+    *out = nullptr;
+    if (channels < 1 || channels > 2 || bytesPerSample < 2 || bytesPerSample > 4)
+        return set_error("unsupported PCM layout"), MFCC_E_WAV;
+    const int rows = channels == 2 ? 4 : channels;
+    if (c->cfg.vecNum > rows) return set_error("vecnum %d > num_channels %d", c->cfg.vecNum, channels), MFCC_E_VECNUM;
+    if (c->cfg.zeroMeanSigFlag && !chanSum2)
+        return set_error("zeroMeanSigFlag needs chanSum2 for a shard plan"), MFCC_E_ARG;
+    const int64_t W = c->cfg.wlen, H = c->cfg.inc;
+    const int64_t total = totalSamples < W ? 0 : (totalSamples - (W - H)) / H;
+    frameBegin = std::max<int64_t>(0, std::min(frameBegin, total));
+    frameEnd = std::max(frameBegin, std::min(frameEnd, total));
+    const int64_t halo = (int64_t)(c->cfg.regreOrder - 1) * c->cfg.delwin;
+    const int64_t eb = std::max<int64_t>(0, frameBegin - halo), ee = std::min(total, frameEnd + halo);
+    std::unique_ptr<MFCCPlan> p(new MFCCPlan);
+    p->ctx = c;
+    p->shard = true;
+    p->channels = channels;
+    p->bps = bytesPerSample;
+    p->numUtts = 1;
+    p->utts.resize(1);
+    UttDesc &d = p->utts[0];
+    memset(&d, 0, sizeof d);
+    const bool empty = frameEnd == frameBegin;
+    const int lead = (!empty && eb * H > 0) ? 1 : 0;
+    p->sampleBegin = empty ? 0 : eb * H - lead;
+    p->sampleCount = empty ? 0 : (ee - 1) * H + W - p->sampleBegin;
+    if (p->sampleCount > 0x7fffffffLL) return set_error("shard longer than 2^31 instants"), MFCC_E_ARG;
+    d.byteOff = 0;
+    d.outRow = 0;
+    d.numInstants = (int32_t)p->sampleCount;
+    d.numFrames = empty ? 0 : (int32_t)(ee - eb);
+    d.lead = lead;
+    d.ownBegin = empty ? 0 : (int32_t)(frameBegin - eb);
+    d.ownCount = (int32_t)(frameEnd - frameBegin);
+    if (c->cfg.zeroMeanSigFlag && totalSamples > 0)
+        for (int r = 0; r < 4; ++r) d.mean[r] = (double)chanSum2[r] / (2.0 * (double)totalSamples);
+    p->totalRows = d.numFrames;
+    p->ownedRowBegin = d.ownBegin;
+    p->ownedRows = d.ownCount;
+    int rc = finish_plan(p.get());
+    if (rc) {
+        MFCCPlanDestroy(p.release());
+        return rc;
+    }
+    *out = p.release();
+    return MFCC_OK;
+}
+
+extern "C" void MFCCPlanDestroy(MFCCPlan *p)
+{
+    if (!p) return;
+    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    (void)hipFree(p->dUtts);
+    (void)hipFree(p->dTileUtt);
+    (void)hipFree(p->dChunkUtt);
+    (void)hipFree(p->dPartial);
+    (void)hipFree(p->dStats);
+    (void)hipFree(p->dSums2);
+    if (p->evStart) (void)hipEventDestroy(p->evStart);
+    if (p->evStop) (void)hipEventDestroy(p->evStop);
+    delete p;
+}
+
+extern "C" int64_t MFCCPlanTotalRows(const MFCCPlan *p) { return p ? p->totalRows : 0; }
+extern "C" int64_t MFCCPlanRowOffset(const MFCCPlan *p, int u)
+{
+    return (p && u >= 0 && u < p->numUtts) ? p->utts[u].outRow : -1;
+}
+extern "C" int64_t MFCCPlanNumFrames(const MFCCPlan *p, int u)
+{
+    return (p && u >= 0 && u < p->numUtts) ? p->utts[u].numFrames : -1;
+}
+extern "C" int64_t MFCCPlanSampleBegin(const MFCCPlan *p) { return p ? p->sampleBegin : 0; }
+extern "C" int64_t MFCCPlanSampleCount(const MFCCPlan *p) { return p ? p->sampleCount : 0; }
+extern "C" int64_t MFCCPlanOwnedRowBegin(const MFCCPlan *p) { return p ? p->ownedRowBegin : 0; }
+extern "C" int64_t MFCCPlanOwnedRows(const MFCCPlan *p) { return p ? p->ownedRows : 0; }
+
+extern "C" int MFCCPlanEnableTiming(MFCCPlan *p, int on)
+{
+    if (!p) return set_error("NULL plan"), MFCC_E_ARG;
+    if (on && !p->evStart) {
+        HIP_TRY(hipSetDevice(p->ctx->device));
+        HIP_TRY(hipEventCreate(&p->evStart));
+        HIP_TRY(hipEventCreate(&p->evStop));
+    }
+    p->timing = on != 0;
+    p->timed = false;
+    return MFCC_OK;
+}
+
+extern "C" float MFCCPlanLastKernelMs(MFCCPlan *p)
+{
+    if (!p || !p->timing || !p->timed) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(p->evStop) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, p->evStart, p->evStop) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// ------------------------------------------------------------------------------------------
+// extraction
+// ------------------------------------------------------------------------------------------
+
+template <typename T>
+static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outDev, void *stream)
+{
+    FrontArgs<T> a;
+    memset(&a, 0, sizeof a);
+    a.pcm = static_cast<const unsigned char *>(pcmDev);
+    a.utts = p->dUtts;
+    a.tileUtt = p->dTileUtt;
+    a.out = static_cast<T *>(outDev);
+    a.numTiles = p->numTiles;
+    a.wlen = c->cfg.wlen;
+    a.inc = c->cfg.inc;
+    a.framesPerTile = p->framesPerTile;
+    a.V = c->cfg.vecNum;
+    a.channels = p->channels;
+    a.bps = p->bps;
+    a.P = c->cfg.bankNum;
+    a.M = c->M;
+    a.D = c->D;
+    a.vSize = c->vSize;
+    a.step = c->step;
+    a.c0Flag = c->c0;
+    a.energyFlag = c->cfg.energyFlag;
+    a.zcFlag = c->cfg.zeroCrossingFlag;
+    a.brightFlag = c->cfg.brightFlag;
+    a.S = c->cfg.subBandEFlag;
+    a.fftLength = c->cfg.fftLength;
+    a.fbankFlag = c->cfg.fbankFlag ? 1 : 0;
+    a.preK = c->cfg.preemphasise;
+    a.mfnorm = (T)c->tab.mfnorm;
+    a.window = static_cast<const T *>(c->dWindow);
+    a.tw = static_cast<const T *>(c->dTw);
+    a.splitTw = static_cast<const T *>(c->dSplitTw);
+    a.loWt = static_cast<const T *>(c->dLoWt);
+    a.chanRange = c->dChanRange;
+    a.dct = static_cast<const T *>(c->dDct);
+    a.rowPitch = p->rowPitch;
+    a.zPitch = front_zpitch(c->tab.log2nc);
+    a.rawOrZElems = p->rawOrZElems;
+    const int rc = launch_front(c->cfg.precision, c->tab.log2nc, &a, p->numTiles, p->ldsBytes, stream);
+    if (rc) return set_error("static-feature kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+template <typename T>
+static int run_regress(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
+{
+    double sigmaT2 = 0.0;
+    for (int t = 1; t <= c->cfg.delwin; ++t) sigmaT2 += (double)t * t;
+    sigmaT2 *= 2.0;
+    for (int order = 2; order <= c->cfg.regreOrder; ++order) { /* main.c:259-260 */
+        RegressArgs<T> a;
+        memset(&a, 0, sizeof a);
+        a.data = static_cast<T *>(outDev);
+        a.utts = p->dUtts;
+        a.tileUtt = p->dTileUtt;
+        a.numTiles = p->numTiles;
+        a.framesPerTile = p->framesPerTile;
+        a.vSize = c->vSize;
+        a.step = c->step;
+        a.srcCol = (order - 2) * c->vSize;
+        a.dstCol = (order - 1) * c->vSize;
+        a.delwin = c->cfg.delwin;
+        a.sigmaT2 = sigmaT2;
+        a.invSigmaT2 = (T)(1.0 / sigmaT2);
+        const int rc = launch_regress(c->cfg.precision, &a, p->numTiles, stream);
+        if (rc) return set_error("regression kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    }
+    return MFCC_OK;
+}
+
+template <typename T>
+static StatArgs<T> stat_args(MFCCContext *c, MFCCPlan *p, void *outDev)
+{
+    StatArgs<T> a;
+    memset(&a, 0, sizeof a);
+    a.data = static_cast<T *>(outDev);
+    a.utts = p->dUtts;
+    a.chunkUtt = p->dChunkUtt;
+    a.numChunks = p->numChunks;
+    a.step = c->step;
+    a.partial = p->dPartial;
+    a.stats = p->dStats;
+    return a;
+}
+
+static int run_colstats(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
+{
+    int rc;
+    if (c->cfg.precision == MFCC_PREC_F64) {
+        StatArgs<double> a = stat_args<double>(c, p, outDev);
+        rc = launch_colstats(1, &a, p->numChunks, stream);
+    } else {
+        StatArgs<float> a = stat_args<float>(c, p, outDev);
+        rc = launch_colstats(0, &a, p->numChunks, stream);
+    }
+    if (rc) return set_error("z-norm statistics kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+static int run_normalize(MFCCContext *c, MFCCPlan *p, void *outDev, bool shard, const double *sums,
+                         void *stream)
+{
+    int rc;
+    if (c->cfg.precision == MFCC_PREC_F64) {
+        StatArgs<double> a = stat_args<double>(c, p, outDev);
+        rc = launch_normalize(1, &a, p->numChunks, shard, sums, stream);
+    } else {
+        StatArgs<float> a = stat_args<float>(c, p, outDev);
+        rc = launch_normalize(0, &a, p->numChunks, shard, sums, stream);
+    }
+    if (rc) return set_error("z-norm kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev, size_t pcmBytes,
+                                 void *outDev, void *stream)
+{
+    if (!c || !p || p->ctx != c) return set_error("plan does not belong to this context"), MFCC_E_ARG;
+    if (p->numTiles == 0) return MFCC_OK;
+    if (!pcmDev || !outDev) return set_error("NULL device buffer"), MFCC_E_ARG;
+    const int64_t bpi = (int64_t)p->channels * p->bps;
+    for (const UttDesc &d : p->utts) // every planned byte must lie inside the caller's buffer
+        if (d.numFrames > 0 && (uint64_t)(d.byteOff + (int64_t)d.numInstants * bpi) > (uint64_t)pcmBytes)
+            return set_error("PCM buffer of %zu bytes is shorter than the plan needs", pcmBytes), MFCC_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc;
+    if (c->cfg.zeroMeanSigFlag && !p->shard) {
+        HIP_TRY(hipMemsetAsync(p->dSums2, 0, (size_t)p->numUtts * 4 * sizeof(unsigned long long), st));
+        rc = launch_uttmeans(static_cast<const unsigned char *>(pcmDev), p->dUtts, p->numUtts,
+                             p->channels, p->bps, p->dSums2, stream);
+        if (rc) return set_error("row-mean kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    }
+    const bool f64 = c->cfg.precision == MFCC_PREC_F64;
+    if (p->timing) HIP_TRY(hipEventRecord(p->evStart, st));
+    rc = f64 ? run_front<double>(c, p, pcmDev, outDev, stream) : run_front<float>(c, p, pcmDev, outDev, stream);
+    if (rc) return rc;
+    if (p->timing) {
+        HIP_TRY(hipEventRecord(p->evStop, st));
+        p->timed = true;
+    }
+    rc = f64 ? run_regress<double>(c, p, outDev, stream) : run_regress<float>(c, p, outDev, stream);
+    if (rc) return rc;
+    if (c->cfg.znormFlag && !p->shard) {
+        if ((rc = run_colstats(c, p, outDev, stream))) return rc;
+        StatArgs<float> fa = stat_args<float>(c, p, nullptr);
+        const int e = launch_colfinal(fa, p->numUtts, stream);
+        if (e) return set_error("z-norm finalise kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
+        if ((rc = run_normalize(c, p, outDev, false, nullptr, stream))) return rc;
+    }
+    return MFCC_OK;
+}
+
+extern "C" int MFCCShardColumnSums(MFCCContext *c, MFCCPlan *p, const void *outDev, double *sumsDev,
+                                   void *stream)
+{
+    if (!c || !p || p->ctx != c || !p->shard || !sumsDev) return set_error("bad argument"), MFCC_E_ARG;
+    if (!c->cfg.znormFlag) return set_error("znormFlag is off"), MFCC_E_CONFIG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (p->numChunks == 0) {
+        HIP_TRY(hipMemsetAsync(sumsDev, 0, (size_t)(2 * c->step + 1) * sizeof(double), static_cast<hipStream_t>(stream)));
+        return MFCC_OK;
+    }
+    if (!outDev) return set_error("NULL device buffer"), MFCC_E_ARG;
+    int rc = run_colstats(c, p, const_cast<void *>(outDev), stream);
+    if (rc) return rc;
+    StatArgs<float> fa = stat_args<float>(c, p, nullptr);
+    const int e = launch_shardfinal(fa, p->numChunks, sumsDev, stream);
+    if (e) return set_error("shard statistics kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+extern "C" int MFCCShardNormalize(MFCCContext *c, MFCCPlan *p, void *outDev, const double *sumsDev,
+                                  void *stream)
+{
+    if (!c || !p || p->ctx != c || !p->shard || !sumsDev) return set_error("bad argument"), MFCC_E_ARG;
+    if (p->numChunks == 0) return MFCC_OK;
+    if (!outDev) return set_error("NULL device buffer"), MFCC_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    return run_normalize(c, p, outDev, true, sumsDev, stream);
+}
+
+extern "C" int MFCCChannelSums(MFCCContext *c, const void *pcmDev, int channels, int bytesPerSample,
+                               int64_t sampleBegin, int64_t count, int64_t *sums2Dev, void *stream)
+{
+    if (!c || !sums2Dev || (count > 0 && !pcmDev)) return set_error("bad argument"), MFCC_E_ARG;
+    if (channels < 1 || channels > 2 || bytesPerSample < 2 || bytesPerSample > 4)
+        return set_error("unsupported PCM layout"), MFCC_E_WAV;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(sums2Dev, 0, 4 * sizeof(int64_t), static_cast<hipStream_t>(stream)));
+    const int rc = launch_chansums(static_cast<const unsigned char *>(pcmDev), channels, bytesPerSample,
+                                   sampleBegin * channels * bytesPerSample, count,
+                                   reinterpret_cast<unsigned long long *>(sums2Dev), stream);
+    if (rc) return set_error("channel-sum kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// file-level entry points
+// ------------------------------------------------------------------------------------------
+
+extern "C" void MFCCFree(void *p) { free(p); }
+
+namespace {
+
+// Contexts are reused across MFCCWapper calls with the same numeric options.
+struct CtxCache {
+    std::mutex mu;
+    std::vector<std::pair<std::string, MFCCContext *>> items;
+    ~CtxCache()
+    {
+        for (auto &it : items) MFCCContextDestroy(it.second);
+    }
+};
+CtxCache g_cache;
+
+std::string cfg_key(const MFCCConfig &c, int device)
+{
+    MFCCConfig k = c;
+    memset(k.fileList, 0, sizeof k.fileList);
+    k.saveType = 0;
+    k.numThreads = 0;
+    std::string s(reinterpret_cast<const char *>(&k), sizeof k);
+    s.append(reinterpret_cast<const char *>(&device), sizeof device);
+    return s;
+}
+
+int cached_context(const MFCCConfig &cfgIn, MFCCContext **out)
+{
+    MFCCConfig cfg;
+    memset(&cfg, 0, sizeof cfg); // zero the padding so the key is well defined
+    cfg.sampleRate = cfgIn.sampleRate, cfg.hipassfre = cfgIn.hipassfre, cfg.lowpassfre = cfgIn.lowpassfre;
+    cfg.preemphasise = cfgIn.preemphasise, cfg.wlen = cfgIn.wlen, cfg.inc = cfgIn.inc, cfg.vecNum = cfgIn.vecNum;
+    cfg.fbankFlag = cfgIn.fbankFlag, cfg.bankNum = cfgIn.bankNum, cfg.MFCCNum = cfgIn.MFCCNum;
+    cfg.MFCC0thFlag = cfgIn.MFCC0thFlag, cfg.energyFlag = cfgIn.energyFlag;
+    cfg.zeroCrossingFlag = cfgIn.zeroCrossingFlag, cfg.brightFlag = cfgIn.brightFlag;
+    cfg.subBandEFlag = cfgIn.subBandEFlag, cfg.fftLength = cfgIn.fftLength, cfg.regreOrder = cfgIn.regreOrder;
+    cfg.delwin = cfgIn.delwin, cfg.zeroMeanSigFlag = cfgIn.zeroMeanSigFlag, cfg.znormFlag = cfgIn.znormFlag;
+    cfg.precision = cfgIn.precision;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+        return set_error("no HIP device available (the library has no CPU path)"), MFCC_E_DEVICE;
+    const std::string key = cfg_key(cfg, device);
+    std::lock_guard<std::mutex> lock(g_cache.mu);
+    for (auto &it : g_cache.items)
+        if (it.first == key) {
+            *out = it.second;
+            return MFCC_OK;
+        }
+    MFCCContext *c = nullptr;
+    const int rc = MFCCContextCreate(&cfg, device, &c);
+    if (rc) return rc;
+    if (g_cache.items.size() >= 8) {
+        MFCCContextDestroy(g_cache.items.front().second);
+        g_cache.items.erase(g_cache.items.begin());
+    }
+    g_cache.items.emplace_back(key, c);
+    *out = c;
+    return MFCC_OK;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+};
+
+// Runs one packed batch (same channel count / sample size) and returns the rows as doubles.
+int extract_packed(MFCCContext *c, const unsigned char *packed, size_t packedBytes, int channels,
+                   int bps, const std::vector<int64_t> &off, const std::vector<int64_t> &ns,
+                   std::vector<double> &rowsOut, std::vector<int64_t> &rowOff, std::vector<int64_t> &frames)
+{
+    MFCCPlan *plan = nullptr;
+    int rc = MFCCPlanCreate(c, channels, bps, (int)off.size(), off.data(), ns.data(), &plan);
+    if (rc) return rc;
+    std::unique_ptr<MFCCPlan, void (*)(MFCCPlan *)> guard(plan, MFCCPlanDestroy);
+    const int64_t rows = MFCCPlanTotalRows(plan);
+    rowOff.resize(off.size());
+    frames.resize(off.size());
+    for (size_t u = 0; u < off.size(); ++u) {
+        rowOff[u] = MFCCPlanRowOffset(plan, (int)u);
+        frames[u] = MFCCPlanNumFrames(plan, (int)u);
+    }
+    rowsOut.assign((size_t)rows * c->step, 0.0);
+    if (rows == 0) return MFCC_OK;
+    const size_t el = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
+    DevBuf dPcm, dOut;
+    HIP_TRY(hipMalloc(&dPcm.p, packedBytes + 16));
+    HIP_TRY(hipMalloc(&dOut.p, (size_t)rows * c->step * el));
+    HIP_TRY(hipMemcpy(dPcm.p, packed, packedBytes, hipMemcpyHostToDevice));
+    rc = MFCCExtractDevice(c, plan, dPcm.p, packedBytes, dOut.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (el == 8) {
+        HIP_TRY(hipMemcpy(rowsOut.data(), dOut.p, rowsOut.size() * 8, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp(rowsOut.size());
+        HIP_TRY(hipMemcpy(tmp.data(), dOut.p, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); ++i) rowsOut[i] = (double)tmp[i];
+    }
+    return MFCC_OK;
+}
+
+} // namespace
+
+extern "C" int MFCCWapperMem(const MFCCConfig *cfg, const void *wavFile, size_t wavLen,
+                             const char *outPath, double **features, long *numFrames, int *step)
+{
+    if (features) *features = nullptr;
+    if (numFrames) *numFrames = 0;
+    if (!cfg || !wavFile) return set_error("NULL argument"), MFCC_E_ARG;
+    WavInfo w;
+    int rc = wav_parse(static_cast<const unsigned char *>(wavFile), wavLen, w);
+    if (rc) return rc;
+    if (cfg->sampleRate != w.sampleRate) /* main.c:192-196 */
+        return set_error("Sample rate not right (config %d, file %d)", cfg->sampleRate, w.sampleRate),
+               MFCC_E_SAMPLE_RATE;
+    MFCCContext *c = nullptr;
+    if ((rc = cached_context(*cfg, &c))) return rc;
+    if (step) *step = c->step;
+    std::vector<int64_t> off(1, 0), ns(1, w.numSamples), rowOff, frames;
+    std::vector<double> rows;
+    const unsigned char *data = static_cast<const unsigned char *>(wavFile) + w.dataOffset;
+    const size_t dataBytes = (size_t)w.numSamples * w.channels * w.bytesPerSample;
+    rc = extract_packed(c, data, dataBytes, w.channels, w.bytesPerSample, off, ns, rows, rowOff, frames);
+    if (rc) return rc;
+    if (numFrames) *numFrames = (long)frames[0];
+    if (outPath && (rc = MFCCWriteFeatures(outPath, rows.data(), (long)frames[0], c->step, cfg->saveType)))
+        return rc;
+    if (features) {
+        double *buf = static_cast<double *>(malloc(std::max<size_t>(rows.size(), 1) * sizeof(double)));
+        if (!buf) return set_error("out of memory"), MFCC_E_NOMEM;
+        if (!rows.empty()) memcpy(buf, rows.data(), rows.size() * sizeof(double));
+        *features = buf;
+    }
+    return MFCC_OK;
+}
+
+extern "C" int MFCCWapper(const MFCCConfig *cfg, const char *wavPath, const char *outPath,
+                          double **features, long *numFrames, int *step)
+{
+    if (features) *features = nullptr;
+    if (numFrames) *numFrames = 0;
+    if (!cfg || !wavPath) return set_error("NULL argument"), MFCC_E_ARG;
+    std::vector<unsigned char> file;
+    const int rc = read_file(wavPath, file);
+    if (rc) return rc;
+    return MFCCWapperMem(cfg, file.data(), file.size(), outPath, features, numFrames, step);
+}
+
+namespace {
+
+struct ListItem {
+    std::string src, dst;
+    std::vector<unsigned char> file;
+    WavInfo w;
+    int status = MFCC_OK;
+    std::string message;
+};
+
+// Extracts and writes items [b, e), all of one PCM layout.
+void run_group(MFCCContext *c, const MFCCConfig &cfg, std::vector<ListItem> &items, size_t b, size_t e)
+{
+    const int channels = items[b].w.channels, bps = items[b].w.bytesPerSample;
+    std::vector<int64_t> off, ns, rowOff, frames;
+    size_t total = 0;
+    for (size_t i = b; i < e; ++i) {
+        off.push_back((int64_t)total);
+        ns.push_back(items[i].w.numSamples);
+        total += ((size_t)items[i].w.numSamples * channels * bps + 15) & ~(size_t)15;
+    }
+    std::vector<unsigned char> packed(std::max<size_t>(total, 16));
+    for (size_t i = b; i < e; ++i)
+        memcpy(packed.data() + off[i - b], items[i].file.data() + items[i].w.dataOffset,
+               (size_t)items[i].w.numSamples * channels * bps);
+    std::vector<double> rows;
+    const int rc = extract_packed(c, packed.data(), total, channels, bps, off, ns, rows, rowOff, frames);
+    if (rc) {
+        for (size_t i = b; i < e; ++i) {
+            items[i].status = rc;
+            items[i].message = MFCCLastError();
+        }
+        return;
+    }
+    // writers: text formatting dominates, so spread the files over numThreads host threads
+    const int nth = std::max(1, std::min<int>(cfg.numThreads, (int)(e - b)));
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nth; ++t)
+        pool.emplace_back([&, t]() {
+            for (size_t i = b + t; i < e; i += nth) {
+                const size_t u = i - b;
+                const int wrc = MFCCWriteFeatures(items[i].dst.c_str(), rows.data() + (size_t)rowOff[u] * c->step,
+                                                  (long)frames[u], c->step, cfg.saveType);
+                if (wrc) {
+                    items[i].status = wrc;
+                    items[i].message = MFCCLastError();
+                }
+            }
+        });
+    for (auto &th : pool) th.join();
+}
+
+} // namespace
+
+extern "C" int MFCCWapperList(const char *iniPath)
+{
+    MFCCConfig cfg;
+    int bad = 0;
+    int rc = MFCCConfigFromIni(iniPath, &cfg, &bad);
+    if (rc) return rc;
+    const bool quiet = getenv("MFCC_QUIET") != nullptr;
+    if (!quiet) printf("finish reading the config.ini\n"); /* main.c:140 */
+    MFCCContext *c = nullptr;
+    if ((rc = cached_context(cfg, &c))) return rc;
+    if (!quiet) {
+        char text[256];
+        MFCCContextPassbandText(c, text, sizeof text);
+        fputs(text, stdout);
+    }
+    FILE *fl = fopen(cfg.fileList, "r");
+    if (!fl) return set_error("open file list %s failed", cfg.fileList), MFCC_E_OPEN;
+    std::vector<ListItem> items;
+    char line[MFCC_MAX_PATH];
+    while (fgets(line, MFCC_MAX_PATH, fl)) { /* main.c:173-177 */
+        if (line[0] == '\n') break;
+        char *src = strtok(line, "\t");
+        char *dst = strtok(nullptr, "\n");
+        ListItem it;
+        it.src = src ? src : "";
+        it.dst = dst ? dst : "";
+        while (!it.dst.empty() && (it.dst.back() == '\r' || it.dst.back() == '\n')) it.dst.pop_back();
+        if (!src || !dst || it.dst.empty()) {
+            it.status = MFCC_E_ARG;
+            it.message = "list line is not \"src<TAB>dst\"";
+        }
+        items.push_back(std::move(it));
+    }
+    fclose(fl);
+
+    int failed = 0;
+    const size_t kBatchBytes = (size_t)1 << 30;
+    size_t i = 0;
+    while (i < items.size()) {
+        // read files until the batch is full or the PCM layout changes
+        size_t b = i, bytes = 0;
+        int ch = 0, bps = 0;
+        while (i < items.size()) {
+            ListItem &it = items[i];
+            if (it.status == MFCC_OK && it.file.empty()) {
+                if (!quiet) printf("Convert %s to %s\n", it.src.c_str(), it.dst.c_str()); /* main.c:180 */
+                int r = read_file(it.src.c_str(), it.file);
+                if (!r) r = wav_parse(it.file.data(), it.file.size(), it.w);
+                if (!r && cfg.sampleRate != it.w.sampleRate) {
+                    set_error("Sample rate not right (config %d, file %d)", cfg.sampleRate, it.w.sampleRate);
+                    r = MFCC_E_SAMPLE_RATE;
+                }
+                if (r) {
+                    it.status = r;
+                    it.message = MFCCLastError();
+                    it.file.clear();
+                }
+            }
+            if (it.status != MFCC_OK) { // a failed file closes the batch; it is skipped
+                ++i;
+                break;
+            }
+            if (ch == 0) {
+                ch = it.w.channels;
+                bps = it.w.bytesPerSample;
+            } else if (ch != it.w.channels || bps != it.w.bytesPerSample) {
+                break; // leave it for the next batch (it is re-read there)
+            }
+            bytes += it.file.size();
+            ++i;
+            if (bytes >= kBatchBytes) break;
+        }
+        // [b, e) holds the readable files of this batch (the last one may be the failed one)
+        size_t e = i;
+        while (e > b && items[e - 1].status != MFCC_OK) --e;
+        if (e > b) run_group(c, cfg, items, b, e);
+        for (size_t k = b; k < i; ++k) {
+            items[k].file.clear();
+            items[k].file.shrink_to_fit();
+        }
+    }
+    for (const ListItem &it : items)
+        if (it.status != MFCC_OK) {
+            ++failed;
+            fprintf(stderr, "mfcc: %s: %s (code %d)\n", it.src.c_str(), it.message.c_str(), it.status);
+        }
+    if (failed) set_error("%d of %zu files failed", failed, items.size());
+    return failed;
+}

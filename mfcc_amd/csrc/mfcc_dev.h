@@ -1,0 +1,92 @@
+// Internal structures shared by the host code and the HIP kernels (not part of the C ABI).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mfcc {
+
+constexpr int kBlock = 256;       // threads per workgroup of every kernel (4 waves of 64)
+constexpr int kMaxLog2Nc = 13;    // fftN <= 16384
+constexpr int kStatRows = 1024;   // rows per workgroup of the z-norm statistics kernels
+
+// One utterance (or one rank's shard of a long recording) as the kernels see it.
+struct UttDesc {
+    int64_t byteOff;    // first byte of instant 0 of this utterance's buffer inside the PCM buffer
+    int64_t outRow;     // output row of local frame 0
+    int32_t numInstants;// sample instants in the buffer (lead instant included)
+    int32_t numFrames;  // frames computed from the buffer (local frames 0 .. numFrames-1)
+    int32_t lead;       // 1: instant 0 only serves as the pre-emphasis predecessor of instant 1
+                        //    (the buffer starts inside a longer recording); 0: instant 0 starts the signal
+    int32_t tileBegin;  // index of this utterance's first tile in the tile table
+    int32_t ownBegin;   // first local frame that enters the z-norm statistics / is normalised
+    int32_t ownCount;   // number of such frames
+    int32_t statBegin;  // index of this utterance's first statistics chunk
+    int32_t pad;
+    double mean[4];     // value subtracted from the derived rows {L, R, mid, side} (0 = option off)
+};
+
+// Arguments of the static-feature kernel.
+template <typename T>
+struct FrontArgs {
+    const unsigned char *pcm;
+    const UttDesc *utts;
+    const int32_t *tileUtt;
+    T *out;
+    int numTiles;
+    int wlen, inc, framesPerTile;
+    int V, channels, bps;
+    int P, M, D, vSize, step;
+    int c0Flag, energyFlag, zcFlag, brightFlag, S, fftLength, fbankFlag;
+    double preK;
+    T mfnorm;
+    const T *window;       // wlen
+    const T *tw;           // nc complex (cos, -sin)(2 pi m / nc), interleaved
+    const T *splitTw;      // nc/2 complex (cos, sin)(pi a / nc), interleaved
+    const T *loWt;         // nc
+    const int32_t *chanRange; // P x 4: [hiBegin, hiEnd) bins taken with (1 - loWt), [loBegin, loEnd) with loWt
+    const T *dct;          // P x M, k-major: cos(pi (j+1) (k + 0.5) / P)
+    int rowPitch;          // elements per derived row in LDS
+    int zPitch;            // elements per frame-group work area in LDS
+    int rawOrZElems;       // elements reserved for max(raw PCM bytes, all work areas)
+};
+
+template <typename T>
+struct RegressArgs {
+    T *data;
+    const UttDesc *utts;
+    const int32_t *tileUtt;
+    int numTiles, framesPerTile;
+    int vSize, step, srcCol, dstCol, delwin;
+    T invSigmaT2;
+    double sigmaT2;
+};
+
+template <typename T>
+struct StatArgs {
+    T *data;
+    const UttDesc *utts;
+    const int32_t *chunkUtt;
+    int numChunks;
+    int step;
+    double *partial; // numChunks x 2*step
+    double *stats;   // numUtts x 2*step : mean, 1/std  (batch plans)  or  shard sums (2*step+1)
+};
+
+int launch_front(int precision, int log2nc, const void *args, int numTiles, size_t ldsBytes,
+                 void *stream);
+size_t front_lds_bytes(int precision, int log2nc, int V, int rowPitch, int zPitch, int rawOrZElems,
+                       int framesPerTile, int vSize, int P);
+int front_groups(int log2nc);   // frame groups per workgroup
+int front_zpitch(int log2nc);   // elements per work area
+int launch_regress(int precision, const void *args, int numTiles, void *stream);
+int launch_colstats(int precision, const void *args, int numChunks, void *stream);
+int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream);
+int launch_shardfinal(const StatArgs<float> &a, int numChunks, double *sumsOut, void *stream);
+int launch_normalize(int precision, const void *args, int numChunks, bool shardSums,
+                     const double *sums, void *stream);
+int launch_chansums(const unsigned char *pcm, int channels, int bps, int64_t firstByte,
+                    int64_t count, unsigned long long *sums2 /*4, pre-zeroed*/, void *stream);
+int launch_uttmeans(const unsigned char *pcm, UttDesc *utts, int numUtts, int channels, int bps,
+                    unsigned long long *sums2 /*numUtts x 4, pre-zeroed*/, void *stream);
+
+} // namespace mfcc

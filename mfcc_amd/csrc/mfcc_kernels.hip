@@ -1,0 +1,765 @@
+// HIP kernels for gfx950 (MI355X): PCM unpack -> pre-emphasis -> framing -> Hamming -> real FFT
+// -> power -> HTK mel filterbank -> log -> DCT / C0 / energy / ZCR / brightness / sub-band energy
+// (one fused kernel), regression deltas, per-utterance z-norm, and integer channel sums.
+//
+// The fused kernel follows the arithmetic of Wave2FBank / FBank2MFCC / FBank2C0 (mfcc.c:125-208)
+// and of the frame loop of main.c:217-250, but is organised for the hardware: one 256-thread
+// workgroup owns a tile of consecutive frames of one utterance, reads the tile's PCM bytes once
+// (16-byte coalesced loads), keeps the pre-emphasised rows in LDS, and gives every (frame, vec)
+// pair to a group of G = nc/16 lanes that hold 16 complex points each in registers.
+#include <hip/hip_runtime.h>
+
+#include "fft_regs.h"
+#include "mfcc_dev.h"
+
+namespace mfcc {
+
+template <int LOG2NC>
+struct Geo {
+    static constexpr int NC = 1 << LOG2NC;                        // complex FFT length = fftN / 2
+    static constexpr int G = NC >= 16 ? (NC / 16 > kBlock ? kBlock : NC / 16) : 1; // lanes per frame
+    static constexpr int PPL = NC / G;                            // complex points per lane
+    static constexpr int GROUPS = kBlock / G;                     // frames in flight per workgroup
+    static constexpr int ZPITCH = 2 * NC + 2;                     // elements per work area
+};
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+
+template <typename V, int G>
+__device__ __forceinline__ V group_sum(V v, V *scratch, int tid)
+{
+    if constexpr (G == 1) {
+        return v;
+    } else if constexpr (G <= 64) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) scratch[tid >> 6] = v;
+        __syncthreads();
+        constexpr int WPG = G / 64; // waves per group
+        const int w0 = (tid / G) * WPG;
+        V s = scratch[w0];
+#pragma unroll
+        for (int w = 1; w < WPG; ++w) s += scratch[w0 + w];
+        return s;
+    }
+}
+
+__device__ __forceinline__ int lds_sample(const unsigned *raw, int p, int bps)
+{
+    const int w = p >> 2;
+    const unsigned v = __builtin_amdgcn_alignbyte(raw[w + 1], raw[w], (unsigned)(p & 3));
+    if (bps == 2) return (int)(short)(v & 0xffffu);
+    if (bps == 3) return ((int)(v << 8)) >> 8;
+    return (int)v;
+}
+
+// x - k * xp with the product and the difference rounded separately, as the reference's
+// un-fused double arithmetic does; keeps the sign of near-cancelling samples exact for the ZCR.
+__device__ __forceinline__ double sub_mul_exact(double x, double xp, double k)
+{
+#pragma clang fp contract(off)
+    const double t = xp * k;
+    return x - t;
+}
+
+template <typename T>
+__device__ __forceinline__ T tlog(T x);
+template <>
+__device__ __forceinline__ float tlog<float>(float x) { return logf(x); }
+template <>
+__device__ __forceinline__ double tlog<double>(double x) { return log(x); }
+template <typename T>
+__device__ __forceinline__ T tsqrt(T x);
+template <>
+__device__ __forceinline__ float tsqrt<float>(float x) { return sqrtf(x); }
+template <>
+__device__ __forceinline__ double tsqrt<double>(double x) { return sqrt(x); }
+
+// ------------------------------------------------------------------------------------------
+// Stockham stages through the LDS work area Z (nc complex), radix <= 16 in registers.
+// Stage with sub-transform size NS: butterfly j reads points j + r*nc/R, multiplies point r by
+// w^{r (j mod NS) nc/(NS R)}, takes the R-point DFT and writes (j/NS) NS R + (j mod NS) + r NS.
+// ------------------------------------------------------------------------------------------
+
+template <typename T, int LOG2NC, int LOGNS>
+__device__ __forceinline__ void fft_stages(cpx<T> (&v)[Geo<LOG2NC>::PPL], cpx<T> *Z, int l,
+                                           const T *__restrict__ tw)
+{
+    using GEO = Geo<LOG2NC>;
+    constexpr int NC = GEO::NC, G = GEO::G, PPL = GEO::PPL;
+    constexpr int RB = (LOG2NC - LOGNS) < 4 ? (LOG2NC - LOGNS) : 4;
+    constexpr int R = 1 << RB, NS = 1 << LOGNS, NB = PPL / R, STRIDE = NC / R;
+    if constexpr (LOGNS > 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int j = l + G * b;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[b * R + r] = Z[j + r * STRIDE];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int j = l + G * b;
+            const int base = (j & (NS - 1)) * (NC / (NS * R));
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                const int idx = r * base;
+                const cpx<T> w = {tw[2 * idx], tw[2 * idx + 1]};
+                v[b * R + r] = cmul(v[b * R + r], w);
+            }
+        }
+        __syncthreads(); // every read of Z is done before any lane overwrites it
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) Radix<T, R>::run(&v[b * R]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = l + G * b;
+        const int o = ((j >> LOGNS) << (LOGNS + RB)) + (j & (NS - 1));
+#pragma unroll
+        for (int r = 0; r < R; ++r) Z[o + r * NS] = v[b * R + r];
+    }
+    __syncthreads();
+    if constexpr (LOGNS + RB < LOG2NC) fft_stages<T, LOG2NC, LOGNS + RB>(v, Z, l, tw);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused static-feature kernel
+// ------------------------------------------------------------------------------------------
+
+template <typename T, int LOG2NC>
+__global__ __launch_bounds__(kBlock) void k_front(const FrontArgs<T> a)
+{
+    using GEO = Geo<LOG2NC>;
+    constexpr int NC = GEO::NC, G = GEO::G, PPL = GEO::PPL, GROUPS = GEO::GROUPS;
+    constexpr int R0B = LOG2NC < 4 ? LOG2NC : 4, R0 = 1 << R0B; // radix of the first stage
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *rows = reinterpret_cast<T *>(smem);          // V x rowPitch pre-emphasised samples
+    T *zbuf = rows + a.V * a.rowPitch;              // GROUPS work areas; raw PCM bytes alias it
+    T *feat = zbuf + a.rawOrZElems;                 // framesPerTile x vSize static features
+    T *fbk = feat + a.framesPerTile * a.vSize;      // GROUPS x P log-mel values
+    T *red = fbk + GROUPS * a.P;                    // 8 elements for cross-wave sums
+    unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
+
+    const int tid = threadIdx.x;
+    const int l = tid & (G - 1), grp = tid / G;
+    const int bpi = a.channels * a.bps;
+
+    for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+        const int u = a.tileUtt[tile];
+        const UttDesc ud = a.utts[u];
+        const int f0 = (tile - ud.tileBegin) * a.framesPerTile;
+        const int nf = min(a.framesPerTile, ud.numFrames - f0);
+        const long long first = (long long)f0 * a.inc + ud.lead; // first instant of the first frame
+        const long long first0 = first > 0 ? first - 1 : 0;      // plus its pre-emphasis predecessor
+        const int ns = (nf - 1) * a.inc + a.wlen;                 // frame samples in the tile
+        const int lead = (int)(first - first0);
+
+        // A1: tile bytes -> LDS, 16-byte aligned vector loads (each block holds >= 1 valid byte)
+        const unsigned char *gbase = a.pcm + ud.byteOff + first0 * bpi;
+        const unsigned long long gaddr = (unsigned long long)gbase;
+        const int mis = (int)(gaddr & 15ull);
+        const uint4 *src = reinterpret_cast<const uint4 *>(gaddr - mis);
+        const int nvec = (mis + (ns + lead) * bpi + 15) >> 4;
+        for (int i = tid; i < nvec; i += kBlock) reinterpret_cast<uint4 *>(raw)[i] = src[i];
+        __syncthreads();
+
+        // A2: unpack, derive {L, R, mid, side}, subtract the row mean, pre-emphasise in double
+        // with separately rounded multiply and subtract (PreEmphasise, call site main.c:208).
+        for (int s = tid; s < ns; s += kBlock) {
+            const int rel = s + lead;
+            const bool hasPrev = (first + s) > 0;
+            double cur[4], prv[4];
+            {
+                const int p = mis + rel * bpi;
+                const int c0 = lds_sample(raw, p, a.bps);
+                const int c1 = a.channels == 2 ? lds_sample(raw, p + a.bps, a.bps) : 0;
+                cur[0] = (double)c0;
+                cur[1] = (double)c1;
+                cur[2] = 0.5 * ((double)c0 + (double)c1);
+                cur[3] = (double)c0 - (double)c1;
+            }
+            if (hasPrev) {
+                const int p = mis + (rel - 1) * bpi;
+                const int c0 = lds_sample(raw, p, a.bps);
+                const int c1 = a.channels == 2 ? lds_sample(raw, p + a.bps, a.bps) : 0;
+                prv[0] = (double)c0;
+                prv[1] = (double)c1;
+                prv[2] = 0.5 * ((double)c0 + (double)c1);
+                prv[3] = (double)c0 - (double)c1;
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (v < a.V) {
+                    const double x = cur[v] - ud.mean[v];
+                    double y;
+                    if (hasPrev)
+                        y = sub_mul_exact(x, prv[v] - ud.mean[v], a.preK);
+                    else
+                        y = x * (1.0 - a.preK);
+                    rows[v * a.rowPitch + s] = (T)y;
+                }
+            }
+        }
+        __syncthreads();
+
+        const int nItems = nf * a.V;
+        for (int base = 0; base < nItems; base += GROUPS) {
+            const int item = base + grp;
+            const bool active = item < nItems;
+            const int fr = active ? item / a.V : 0, vv = active ? item - fr * a.V : 0;
+            const T *x = rows + vv * a.rowPitch + fr * a.inc;
+            cpx<T> *Z = reinterpret_cast<cpx<T> *>(zbuf + grp * GEO::ZPITCH);
+            T *Pw = zbuf + grp * GEO::ZPITCH;
+            T *fo = feat + item * a.D;
+
+            // ---- window, frame energy, zero crossings, first FFT stage input (Ham main.c:229,
+            //      te mfcc.c:138-142, zero padding mfcc.c:144-147)
+            cpx<T> v[PPL];
+            T te = 0;
+            int zc = 0;
+#pragma unroll
+            for (int b = 0; b < PPL / R0; ++b) {
+#pragma unroll
+                for (int r = 0; r < R0; ++r) {
+                    const int n = l + G * b + r * (NC / R0);
+                    const int s0 = 2 * n, s1 = s0 + 1;
+                    T x0 = 0, x1 = 0, x2 = 0;
+                    if (active && s0 < a.wlen) x0 = x[s0];
+                    if (active && s1 < a.wlen) x1 = x[s1];
+                    if (a.zcFlag) {
+                        if (active && s1 + 1 < a.wlen) x2 = x[s1 + 1];
+                        zc += ((x0 < 0 && x1 > 0) || (x0 > 0 && x1 < 0)) ? 1 : 0;
+                        zc += ((x1 < 0 && x2 > 0) || (x1 > 0 && x2 < 0)) ? 1 : 0;
+                    }
+                    const T w0 = s0 < a.wlen ? a.window[s0] : (T)0;
+                    const T w1 = s1 < a.wlen ? a.window[s1] : (T)0;
+                    x0 *= w0;
+                    x1 *= w1;
+                    te += x0 * x0 + x1 * x1;
+                    v[b * R0 + r] = {x0, x1};
+                }
+            }
+            if (a.energyFlag) te = group_sum<T, G>(te, red, tid);
+            if (a.zcFlag) zc = group_sum<int, G>(zc, reinterpret_cast<int *>(red), tid);
+
+            // ---- nc-point complex FFT of z[n] = x[2n] + i x[2n+1]   (Realft mfcc.c:262-270)
+            fft_stages<T, LOG2NC, 0>(v, Z, l, a.tw);
+
+            // ---- real-FFT split and power  (mfcc.c:274-290, ek of mfcc.c:153-155)
+            // X[k] = E + w O, X[nc-k] = conj(E - w O), w = exp(-i pi k / nc); only |X|^2 is kept.
+            T pa[PPL / 2 > 0 ? PPL / 2 : 1], pb[PPL / 2 > 0 ? PPL / 2 : 1];
+#pragma unroll
+            for (int q = 0; q < (PPL / 2 > 0 ? PPL / 2 : 1); ++q) {
+                const int k = l + G * q;
+                if (k == 0) {
+                    const cpx<T> z0 = Z[0], zh = Z[NC / 2];
+                    pa[q] = (z0.x + z0.y) * (z0.x + z0.y);
+                    pb[q] = NC > 1 ? zh.x * zh.x + zh.y * zh.y : (T)0;
+                } else {
+                    const cpx<T> za = Z[k], zb = Z[NC - k];
+                    const T c = a.splitTw[2 * k], s = a.splitTw[2 * k + 1];
+                    const T ex = (T)0.5 * (za.x + zb.x), ey = (T)0.5 * (za.y - zb.y);
+                    const T ox = (T)0.5 * (za.y + zb.y), oy = (T)-0.5 * (za.x - zb.x);
+                    const T wx = c * ox + s * oy, wy = c * oy - s * ox;
+                    pa[q] = (ex + wx) * (ex + wx) + (ey + wy) * (ey + wy);
+                    pb[q] = (ex - wx) * (ex - wx) + (ey - wy) * (ey - wy);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < (PPL / 2 > 0 ? PPL / 2 : 1); ++q) {
+                const int k = l + G * q;
+                if (k == 0) {
+                    Pw[0] = pa[q];
+                    if (NC > 1) Pw[NC / 2] = pb[q];
+                } else {
+                    Pw[k] = pa[q];
+                    Pw[NC - k] = pb[q];
+                }
+            }
+            __syncthreads();
+
+            // ---- brightness and sub-band energies (call sites main.c:235-236)
+            if (a.brightFlag || a.S > 0) {
+                const int nseg = a.S > 0 ? a.S : 1;
+                const int width = NC / nseg;
+                const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
+                T total = 0, num = 0;
+                for (int g = 0; g < nseg; ++g) {
+                    const int lo = g * width, hi = (g == nseg - 1) ? NC : lo + width;
+                    T e = 0, ek = 0;
+                    for (int k = lo + l; k < hi; k += G) {
+                        const T pv = Pw[k];
+                        e += pv;
+                        ek += (T)(k + 1) * pv;
+                    }
+                    e = group_sum<T, G>(e, red, tid);
+                    ek = group_sum<T, G>(ek, red, tid);
+                    if (active && l == 0 && a.S > 0) fo[subAt + g] = e;
+                    total += e;
+                    num += ek;
+                }
+                if (active && l == 0) {
+                    if (a.brightFlag)
+                        fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / total / (T)NC;
+                    for (int g = 0; g < a.S; ++g) fo[subAt + g] = fo[subAt + g] / total;
+                }
+            }
+            if (active && l == 0) {
+                if (a.energyFlag) fo[a.M + a.c0Flag] = tlog<T>(te);                // main.c:243
+                if (a.zcFlag)
+                    fo[a.M + a.c0Flag + a.energyFlag] = (T)zc / (T)(a.wlen - 1);   // main.c:244
+            }
+            if (active && a.fftLength > 0) {                                       // main.c:247
+                const int at = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag + a.S;
+                for (int q = l; q < a.fftLength; q += G) fo[at + q] = tsqrt<T>(Pw[q]);
+            }
+
+            // ---- mel filterbank, gather form of the two-tap scatter of mfcc.c:152-163, then
+            //      log(max(., 1))  (mfcc.c:171-176)
+            if (active) {
+                for (int ch = l; ch < a.P; ch += G) {
+                    const int4 rg = reinterpret_cast<const int4 *>(a.chanRange)[ch];
+                    T acc = 0;
+                    for (int k = rg.x; k < rg.y; ++k) {
+                        const T pv = Pw[k];
+                        acc += pv - a.loWt[k] * pv;
+                    }
+                    for (int k = rg.z; k < rg.w; ++k) acc += a.loWt[k] * Pw[k];
+                    const T lv = tlog<T>(acc < (T)1 ? (T)1 : acc);
+                    fbk[grp * a.P + ch] = lv;
+                    if (a.fbankFlag) fo[ch] = lv;
+                }
+            }
+            __syncthreads();
+
+            // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208)
+            if (active && !a.fbankFlag) {
+                const T *fb = fbk + grp * a.P;
+                for (int j = l; j < a.M + a.c0Flag; j += G) {
+                    T acc = 0;
+                    if (j < a.M) {
+                        for (int k = 0; k < a.P; ++k) acc += fb[k] * a.dct[k * a.M + j];
+                    } else {
+                        for (int k = 0; k < a.P; ++k) acc += fb[k];
+                    }
+                    fo[j] = acc * a.mfnorm;
+                }
+            }
+            // the next round overwrites the work areas and fbk: all lanes must be done reading
+            __syncthreads();
+        }
+
+        // ---- tile rows -> HBM (static block of every row; delta slots are written later)
+        const long long row0 = ud.outRow + f0;
+        for (int i = tid; i < nf * a.vSize; i += kBlock) {
+            const int r = i / a.vSize, c = i - r * a.vSize;
+            a.out[(row0 + r) * a.step + c] = feat[i];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Regression deltas (HTK Regress with head = tail = 0, call sites main.c:259-260)
+// ------------------------------------------------------------------------------------------
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_regress(const RegressArgs<T> a)
+{
+    for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
+        const int u = a.tileUtt[tile];
+        const UttDesc ud = a.utts[u];
+        const int f0 = (tile - ud.tileBegin) * a.framesPerTile;
+        const int nf = min(a.framesPerTile, ud.numFrames - f0);
+        const int n = ud.numFrames;
+        T *base = a.data + ud.outRow * a.step;
+        for (int i = threadIdx.x; i < nf * a.vSize; i += kBlock) {
+            const int r = i / a.vSize, c = i - r * a.vSize;
+            const int t0 = f0 + r;
+            int back = t0, forw = t0;
+            T sum = 0;
+            for (int t = 1; t <= a.delwin; ++t) {
+                if (t0 - t >= 0) --back;
+                if (t0 + t <= n - 1) ++forw;
+                sum += (T)t * (base[(long long)forw * a.step + a.srcCol + c] -
+                               base[(long long)back * a.step + a.srcCol + c]);
+            }
+            base[(long long)t0 * a.step + a.dstCol + c] = (T)((double)sum / a.sigmaT2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// z-norm: per-chunk column sums (double), per-utterance finalise, normalise
+// ------------------------------------------------------------------------------------------
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_colstats(const StatArgs<T> a)
+{
+    __shared__ double sh[2 * kBlock];
+    const int chunk = blockIdx.x;
+    const int u = a.chunkUtt[chunk];
+    const UttDesc ud = a.utts[u];
+    const int r0 = (chunk - ud.statBegin) * kStatRows;
+    const int nr = min(kStatRows, ud.ownCount - r0);
+    const T *base = a.data + (ud.outRow + ud.ownBegin + r0) * a.step;
+    for (int c0 = 0; c0 < a.step; c0 += kBlock) {
+        const int ncol = min(kBlock, a.step - c0);
+        const int lanesPerRow = ncol;
+        const int rowLanes = kBlock / lanesPerRow;
+        const int col = threadIdx.x % lanesPerRow, rl = threadIdx.x / lanesPerRow;
+        double s = 0, s2 = 0;
+        if (rl < rowLanes)
+            for (int r = rl; r < nr; r += rowLanes) {
+                const double x = (double)base[(long long)r * a.step + c0 + col];
+                s += x;
+                s2 += x * x;
+            }
+        sh[threadIdx.x] = s;
+        sh[kBlock + threadIdx.x] = s2;
+        __syncthreads();
+        if (threadIdx.x < ncol) {
+            double t = 0, t2 = 0;
+            for (int q = 0; q < rowLanes; ++q) {
+                t += sh[q * lanesPerRow + threadIdx.x];
+                t2 += sh[kBlock + q * lanesPerRow + threadIdx.x];
+            }
+            a.partial[(long long)chunk * 2 * a.step + c0 + threadIdx.x] = t;
+            a.partial[(long long)chunk * 2 * a.step + a.step + c0 + threadIdx.x] = t2;
+        }
+        __syncthreads();
+    }
+}
+
+// One workgroup per utterance: chunk partials summed in chunk order -> mean and 1/std.
+__global__ __launch_bounds__(kBlock) void k_colfinal(const UttDesc *utts, const double *partial,
+                                                     double *stats, int step)
+{
+    const int u = blockIdx.x;
+    const UttDesc ud = utts[u];
+    const int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
+    for (int c = threadIdx.x; c < step; c += kBlock) {
+        double s = 0, s2 = 0;
+        for (int q = 0; q < nchunk; ++q) {
+            s += partial[(long long)(ud.statBegin + q) * 2 * step + c];
+            s2 += partial[(long long)(ud.statBegin + q) * 2 * step + step + c];
+        }
+        const double n = (double)ud.ownCount;
+        const double mean = s / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0) var = 0;
+        stats[(long long)u * 2 * step + c] = mean;
+        stats[(long long)u * 2 * step + step + c] = 1.0 / sqrt(var);
+    }
+}
+
+// Shard plans: one utterance; raw sums out (sum x, sum x^2 per column, then the row count).
+__global__ __launch_bounds__(kBlock) void k_shardfinal(const UttDesc *utts, const double *partial,
+                                                       double *sums, int step)
+{
+    const UttDesc ud = utts[0];
+    const int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
+    for (int c = threadIdx.x; c < 2 * step; c += kBlock) {
+        double s = 0;
+        for (int q = 0; q < nchunk; ++q) s += partial[(long long)(ud.statBegin + q) * 2 * step + c];
+        sums[c] = s;
+    }
+    if (threadIdx.x == 0) sums[2 * step] = (double)ud.ownCount;
+}
+
+// SHARD: sums holds all-reduced {sum x, sum x^2 per column, count}; otherwise stats holds the
+// per-utterance {mean, 1/std}.  Dynamic LDS: 2*step doubles (mean, 1/std of this chunk's utterance).
+template <typename T, bool SHARD>
+__global__ __launch_bounds__(kBlock) void k_normalize(const StatArgs<T> a, const double *sums)
+{
+    extern __shared__ __attribute__((aligned(16))) double shn[];
+    const int chunk = blockIdx.x;
+    const int u = a.chunkUtt[chunk];
+    const UttDesc ud = a.utts[u];
+    const int r0 = (chunk - ud.statBegin) * kStatRows;
+    const int nr = min(kStatRows, ud.ownCount - r0);
+    T *base = a.data + (ud.outRow + ud.ownBegin + r0) * a.step;
+    for (int c = threadIdx.x; c < a.step; c += kBlock) {
+        if constexpr (SHARD) {
+            const double n = sums[2 * a.step];
+            const double mean = sums[c] / n;
+            double var = sums[a.step + c] / n - mean * mean;
+            if (var < 0) var = 0;
+            shn[c] = mean;
+            shn[a.step + c] = 1.0 / sqrt(var);
+        } else {
+            shn[c] = a.stats[(long long)u * 2 * a.step + c];
+            shn[a.step + c] = a.stats[(long long)u * 2 * a.step + a.step + c];
+        }
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < a.step; c0 += kBlock) {
+        const int ncol = min(kBlock, a.step - c0);
+        const int rowLanes = kBlock / ncol;
+        const int col = threadIdx.x % ncol, rl = threadIdx.x / ncol;
+        if (rl >= rowLanes) continue;
+        const double mean = shn[c0 + col], rstd = shn[a.step + c0 + col];
+        for (int r = rl; r < nr; r += rowLanes) {
+            T *p = base + (long long)r * a.step + c0 + col;
+            *p = (T)(((double)*p - mean) * rstd);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Integer channel sums for the zero-mean option: 2*sum of {L, R, mid, side}
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int gmem_sample(const unsigned char *p, int bps)
+{
+    if (bps == 2) return (int)(short)((unsigned)p[0] | ((unsigned)p[1] << 8));
+    if (bps == 3) {
+        const unsigned v = (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16);
+        return ((int)(v << 8)) >> 8;
+    }
+    return (int)((unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16) |
+                 ((unsigned)p[3] << 24));
+}
+
+__device__ __forceinline__ void block_add4(long long sL, long long sR, unsigned long long *dst)
+{
+    __shared__ long long shL[kBlock / 64], shR[kBlock / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sL += __shfl_xor(sL, o, 64);
+        sR += __shfl_xor(sR, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        shL[threadIdx.x >> 6] = sL;
+        shR[threadIdx.x >> 6] = sR;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long L = 0, R = 0;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            L += shL[w];
+            R += shR[w];
+        }
+        atomicAdd(dst + 0, (unsigned long long)(2 * L));
+        atomicAdd(dst + 1, (unsigned long long)(2 * R));
+        atomicAdd(dst + 2, (unsigned long long)(L + R));
+        atomicAdd(dst + 3, (unsigned long long)(2 * (L - R)));
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void k_chansums(const unsigned char *pcm, int channels, int bps,
+                                                     long long firstByte, long long count,
+                                                     unsigned long long *sums2)
+{
+    const int bpi = channels * bps;
+    long long sL = 0, sR = 0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < count;
+         i += (long long)gridDim.x * kBlock) {
+        const unsigned char *p = pcm + firstByte + i * bpi;
+        sL += gmem_sample(p, bps);
+        if (channels == 2) sR += gmem_sample(p + bps, bps);
+    }
+    block_add4(sL, sR, sums2);
+}
+
+// grid = (blocksPerUtt, numUtts): integer sums of one utterance each.
+__global__ __launch_bounds__(kBlock) void k_uttsums(const unsigned char *pcm, const UttDesc *utts,
+                                                    int channels, int bps,
+                                                    unsigned long long *sums2)
+{
+    const UttDesc ud = utts[blockIdx.y];
+    const int bpi = channels * bps;
+    long long sL = 0, sR = 0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < ud.numInstants;
+         i += (long long)gridDim.x * kBlock) {
+        const unsigned char *p = pcm + ud.byteOff + i * bpi;
+        sL += gmem_sample(p, bps);
+        if (channels == 2) sR += gmem_sample(p + bps, bps);
+    }
+    block_add4(sL, sR, sums2 + 4 * blockIdx.y);
+}
+
+__global__ void k_uttmeans(UttDesc *utts, int numUtts, const unsigned long long *sums2)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= numUtts) return;
+    const double n2 = 2.0 * (double)utts[u].numInstants;
+    for (int r = 0; r < 4; ++r)
+        utts[u].mean[r] = n2 > 0 ? (double)(long long)sums2[4 * u + r] / n2 : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+
+#define MFCC_HIP_OK(expr)                     \
+    do {                                      \
+        hipError_t e_ = (expr);               \
+        if (e_ != hipSuccess) return (int)e_; \
+    } while (0)
+
+template <typename T, int L>
+static int launch_front_t(const FrontArgs<T> &a, int numBlocks, size_t lds, hipStream_t st)
+{
+    static bool attrSet[16] = {};
+    int dev = 0;
+    MFCC_HIP_OK(hipGetDevice(&dev));
+    if (dev < 16 && !attrSet[dev]) {
+        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attrSet[dev] = true;
+    }
+    hipLaunchKernelGGL((k_front<T, L>), dim3(numBlocks), dim3(kBlock), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch_front_p(int log2nc, const void *args, int numBlocks, size_t lds, hipStream_t st)
+{
+    const FrontArgs<T> &a = *static_cast<const FrontArgs<T> *>(args);
+    switch (log2nc) {
+#define MFCC_CASE(L) \
+    case L: return launch_front_t<T, L>(a, numBlocks, lds, st);
+        MFCC_CASE(1) MFCC_CASE(2) MFCC_CASE(3) MFCC_CASE(4) MFCC_CASE(5) MFCC_CASE(6) MFCC_CASE(7)
+        MFCC_CASE(8) MFCC_CASE(9) MFCC_CASE(10) MFCC_CASE(11) MFCC_CASE(12) MFCC_CASE(13)
+#undef MFCC_CASE
+    default: return -1;
+    }
+}
+
+int launch_front(int precision, int log2nc, const void *args, int numTiles, size_t ldsBytes,
+                 void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (numTiles <= 0) return 0;
+    return precision == 1 ? launch_front_p<double>(log2nc, args, numTiles, ldsBytes, st)
+                          : launch_front_p<float>(log2nc, args, numTiles, ldsBytes, st);
+}
+
+int front_groups(int log2nc)
+{
+    const int nc = 1 << log2nc;
+    const int g = nc >= 16 ? (nc / 16 > kBlock ? kBlock : nc / 16) : 1;
+    return kBlock / g;
+}
+
+int front_zpitch(int log2nc) { return 2 * (1 << log2nc) + 2; }
+
+size_t front_lds_bytes(int precision, int log2nc, int V, int rowPitch, int zPitch, int rawOrZElems,
+                       int framesPerTile, int vSize, int P)
+{
+    (void)zPitch;
+    const size_t el = precision == 1 ? 8 : 4;
+    const size_t n = (size_t)V * rowPitch + rawOrZElems + (size_t)framesPerTile * vSize +
+                     (size_t)front_groups(log2nc) * P + 8;
+    return n * el;
+}
+
+int launch_regress(int precision, const void *args, int numTiles, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (numTiles <= 0) return 0;
+    if (precision == 1)
+        hipLaunchKernelGGL(k_regress<double>, dim3(numTiles), dim3(kBlock), 0, st,
+                           *static_cast<const RegressArgs<double> *>(args));
+    else
+        hipLaunchKernelGGL(k_regress<float>, dim3(numTiles), dim3(kBlock), 0, st,
+                           *static_cast<const RegressArgs<float> *>(args));
+    return (int)hipGetLastError();
+}
+
+int launch_colstats(int precision, const void *args, int numChunks, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (numChunks <= 0) return 0;
+    if (precision == 1)
+        hipLaunchKernelGGL(k_colstats<double>, dim3(numChunks), dim3(kBlock), 0, st,
+                           *static_cast<const StatArgs<double> *>(args));
+    else
+        hipLaunchKernelGGL(k_colstats<float>, dim3(numChunks), dim3(kBlock), 0, st,
+                           *static_cast<const StatArgs<float> *>(args));
+    return (int)hipGetLastError();
+}
+
+int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream)
+{
+    if (numUtts <= 0) return 0;
+    hipLaunchKernelGGL(k_colfinal, dim3(numUtts), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       a.utts, a.partial, a.stats, a.step);
+    return (int)hipGetLastError();
+}
+
+int launch_shardfinal(const StatArgs<float> &a, int numChunks, double *sumsOut, void *stream)
+{
+    (void)numChunks;
+    hipLaunchKernelGGL(k_shardfinal, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       a.utts, a.partial, sumsOut, a.step);
+    return (int)hipGetLastError();
+}
+
+int launch_normalize(int precision, const void *args, int numChunks, bool shardSums,
+                     const double *sums, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (numChunks <= 0) return 0;
+    const size_t lds = 2 * sizeof(double) *
+                       (size_t)(precision == 1 ? static_cast<const StatArgs<double> *>(args)->step
+                                               : static_cast<const StatArgs<float> *>(args)->step);
+    if (precision == 1) {
+        const StatArgs<double> &a = *static_cast<const StatArgs<double> *>(args);
+        if (shardSums)
+            hipLaunchKernelGGL((k_normalize<double, true>), dim3(numChunks), dim3(kBlock), lds, st, a,
+                               sums);
+        else
+            hipLaunchKernelGGL((k_normalize<double, false>), dim3(numChunks), dim3(kBlock), lds, st,
+                               a, sums);
+    } else {
+        const StatArgs<float> &a = *static_cast<const StatArgs<float> *>(args);
+        if (shardSums)
+            hipLaunchKernelGGL((k_normalize<float, true>), dim3(numChunks), dim3(kBlock), lds, st, a,
+                               sums);
+        else
+            hipLaunchKernelGGL((k_normalize<float, false>), dim3(numChunks), dim3(kBlock), lds, st, a,
+                               sums);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_chansums(const unsigned char *pcm, int channels, int bps, int64_t firstByte,
+                    int64_t count, unsigned long long *sums2, void *stream)
+{
+    if (count <= 0) return 0;
+    long long blocks = (count + kBlock * 16 - 1) / (kBlock * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_chansums, dim3((unsigned)blocks), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), pcm, channels, bps, (long long)firstByte,
+                       (long long)count, sums2);
+    return (int)hipGetLastError();
+}
+
+int launch_uttmeans(const unsigned char *pcm, UttDesc *utts, int numUtts, int channels, int bps,
+                    unsigned long long *sums2, void *stream)
+{
+    if (numUtts <= 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int bx = numUtts >= 2048 ? 1 : (numUtts >= 64 ? 8 : 256);
+    hipLaunchKernelGGL(k_uttsums, dim3(bx, numUtts), dim3(kBlock), 0, st, pcm, utts, channels, bps,
+                       sums2);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_uttmeans, dim3((numUtts + 255) / 256), dim3(256), 0, st, utts, numUtts,
+                       sums2);
+    return (int)hipGetLastError();
+}
+
+} // namespace mfcc

@@ -1,0 +1,123 @@
+// One-time host tables, computed in double and uploaded by the context:
+//   filterbank set-up (replaces InitFBank / Mel, mfcc.c:11-14,39-122; alpha == 1.0 as at the
+//   only call site main.c:168), Hamming window (GenHamWindow, call site main.c:171), DCT matrix
+//   (the cos() of mfcc.c:192 hoisted out of the frame loop) and FFT twiddles.
+#include <math.h>
+
+#include "mfcc_host.h"
+
+namespace mfcc {
+
+static double mel_of_bin(int k, double fres) { return 1127 * log(1 + (k - 1) * fres); } // mfcc.c:13
+
+int build_tables(const MFCCConfig &cfg, Tables &t)
+{
+    const double sampPeriod = 1e7 / (double)cfg.sampleRate; // main.c:141
+    const int P = cfg.bankNum, maxChan = P + 1;
+    t.fftN = 2;
+    while (cfg.wlen > t.fftN) t.fftN *= 2; // mfcc.c:53-54
+    t.nc = t.fftN / 2;
+    t.log2nc = 0;
+    while ((1 << t.log2nc) < t.nc) ++t.log2nc;
+    const int half = t.nc;
+    t.fres = 1.0E7 / (sampPeriod * t.fftN * 700.0); // mfcc.c:58
+
+    // pass band, mfcc.c:61-73
+    t.klo = 2;
+    t.khi = half;
+    t.mlo = 0;
+    t.mhi = mel_of_bin(half + 1, t.fres);
+    if (cfg.lowpassfre >= 0.0) {
+        t.mlo = 1127 * log(1 + cfg.lowpassfre / 700.0);
+        t.klo = (int)((cfg.lowpassfre * sampPeriod * 1.0e-7 * t.fftN) + 2.5);
+        if (t.klo < 2) t.klo = 2;
+    }
+    if (cfg.hipassfre >= 0.0) {
+        t.mhi = 1127 * log(1 + cfg.hipassfre / 700.0);
+        t.khi = (int)((cfg.hipassfre * sampPeriod * 1.0e-7 * t.fftN) + 0.5);
+        if (t.khi > half) t.khi = half;
+    }
+
+    // centre frequencies, mfcc.c:77-82
+    t.cf.assign(maxChan, 0.0);
+    const double ms = t.mhi - t.mlo;
+    for (int chan = 1; chan <= maxChan; ++chan)
+        t.cf[chan - 1] = ((double)chan / (double)maxChan) * ms + t.mlo;
+
+    // lower channel of each bin, mfcc.c:96-104
+    t.loChan.assign(half, -1);
+    for (int k = 1, chan = 1; k <= half; ++k) {
+        if (k < t.klo || k > t.khi) continue;
+        const double melk = mel_of_bin(k, t.fres);
+        while (chan <= maxChan && t.cf[chan - 1] < melk) ++chan;
+        t.loChan[k - 1] = chan - 1;
+    }
+    // lower-channel weights, mfcc.c:107-118
+    t.loWt.assign(half, 0.0);
+    for (int k = t.klo; k <= t.khi && k <= half; ++k) {
+        const int chan = t.loChan[k - 1];
+        const double melk = mel_of_bin(k, t.fres);
+        if (chan > 0)
+            t.loWt[k - 1] = (t.cf[chan] - melk) / (t.cf[chan] - t.cf[chan - 1]);
+        else
+            t.loWt[k - 1] = (t.cf[0] - melk) / (t.cf[0] - t.mlo);
+    }
+    // Gather form of the scatter in mfcc.c:159-162: channel b (1-based) receives (1 - loWt) of
+    // the bins whose lower channel is b-1 and loWt of the bins whose lower channel is b.  loChan
+    // is non-decreasing over the pass band, so both sets are contiguous bin ranges.
+    t.chanRange.assign(4 * (size_t)P, 0);
+    for (int b = 1; b <= P; ++b) {
+        int hi0 = -1, hi1 = -1, lo0 = -1, lo1 = -1;
+        for (int k = 0; k < half; ++k) {
+            if (t.loChan[k] == b - 1) {
+                if (hi0 < 0) hi0 = k;
+                hi1 = k + 1;
+            }
+            if (t.loChan[k] == b) {
+                if (lo0 < 0) lo0 = k;
+                lo1 = k + 1;
+            }
+        }
+        t.chanRange[4 * (b - 1) + 0] = hi0 < 0 ? 0 : hi0;
+        t.chanRange[4 * (b - 1) + 1] = hi0 < 0 ? 0 : hi1;
+        t.chanRange[4 * (b - 1) + 2] = lo0 < 0 ? 0 : lo0;
+        t.chanRange[4 * (b - 1) + 3] = lo0 < 0 ? 0 : lo1;
+    }
+
+    // Hamming window: HTK GenHamWindow, w[i] = 0.54 - 0.46 cos(2 pi (i-1) / (W-1))
+    t.window.resize(cfg.wlen);
+    {
+        const double a = kHtkTwoPi / (cfg.wlen - 1);
+        for (int i = 0; i < cfg.wlen; ++i) t.window[i] = 0.54 - 0.46 * cos(a * i);
+    }
+
+    // DCT-II rows 1..M, k-major; scale sqrt(2/P) applied after the sum as mfcc.c:193 does
+    const int M = eff_mfccnum(cfg);
+    t.mfnorm = sqrt(2.0 / (double)P);
+    t.dct.assign((size_t)P * M, 0.0);
+    {
+        const double piFactor = kHtkPi / (double)P;
+        for (int j = 1; j <= M; ++j) {
+            const double x = (double)j * piFactor;
+            for (int k = 1; k <= P; ++k) t.dct[(size_t)(k - 1) * M + (j - 1)] = cos(x * (k - 0.5));
+        }
+    }
+
+    // FFT twiddles exp(-2 pi i m / nc) and real-FFT split factors (cos, sin)(pi a / nc)
+    t.tw.resize(2 * (size_t)t.nc);
+    for (int m = 0; m < t.nc; ++m) {
+        const double ang = 2.0 * M_PI * (double)m / (double)t.nc;
+        t.tw[2 * m] = cos(ang);
+        t.tw[2 * m + 1] = -sin(ang);
+    }
+    const int nsplit = t.nc / 2 > 0 ? t.nc / 2 : 1;
+    t.splitTw.resize(2 * (size_t)nsplit);
+    for (int a = 0; a < nsplit; ++a) {
+        const double ang = M_PI * (double)a / (double)t.nc;
+        t.splitTw[2 * a] = cos(ang);
+        t.splitTw[2 * a + 1] = sin(ang);
+    }
+    return MFCC_OK;
+}
+
+} // namespace mfcc

@@ -1,0 +1,190 @@
+// Containers: RIFF/WAVE header walk (replaces loadWAVEFile, call site main.c:190-191), feature
+// writers (main.c:272-287 text layouts; cnpy.hpp:88-131,235-264 npy layout; raw binary) and the
+// synthetic PCM generator used by the benchmark and tests.  Host-only code.
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "mfcc_host.h"
+
+namespace mfcc {
+
+static uint32_t le32(const unsigned char *p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+static uint32_t le16(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+// Walks the chunk list: "fmt " gives the format, anything else before "data" is skipped
+// (README.md:68 allows extra chunks between the 44-byte header and the data chunk).
+int wav_parse(const unsigned char *f, size_t len, WavInfo &w)
+{
+    if (!f || len < 12 || memcmp(f, "RIFF", 4) != 0 || memcmp(f + 8, "WAVE", 4) != 0)
+        return set_error("not a RIFF/WAVE file"), MFCC_E_WAV;
+    size_t pos = 12;
+    bool haveFmt = false;
+    int blockAlign = 0;
+    while (pos + 8 <= len) {
+        const uint32_t sz = le32(f + pos + 4);
+        const unsigned char *body = f + pos + 8;
+        if (!memcmp(f + pos, "fmt ", 4)) {
+            if (sz < 16 || pos + 8 + 16 > len) return set_error("short fmt chunk"), MFCC_E_WAV;
+            const uint32_t tag = le16(body);
+            if (tag != 1 && tag != 0xFFFE)
+                return set_error("WAVE format tag %u is not PCM", tag), MFCC_E_WAV;
+            w.channels = (int)le16(body + 2);
+            w.sampleRate = (int)le32(body + 4);
+            blockAlign = (int)le16(body + 12);
+            const int bits = (int)le16(body + 14);
+            w.bytesPerSample = bits / 8;
+            if (bits % 8 != 0 || w.bytesPerSample < 2 || w.bytesPerSample > 4)
+                return set_error("%d-bit PCM is not supported (16, 24 or 32)", bits), MFCC_E_WAV;
+            if (w.channels < 1 || w.channels > 2)
+                return set_error("%d channels are not supported (1 or 2)", w.channels), MFCC_E_WAV;
+            if (blockAlign != w.channels * w.bytesPerSample)
+                return set_error("block align %d != channels x sample size", blockAlign), MFCC_E_WAV;
+            haveFmt = true;
+        } else if (!memcmp(f + pos, "data", 4)) {
+            if (!haveFmt) return set_error("data chunk before fmt chunk"), MFCC_E_WAV;
+            size_t bytes = sz, avail = len - (pos + 8);
+            if (bytes > avail) bytes = avail; // size field that overflowed or was never patched
+            w.numSamples = (long)(bytes / (size_t)blockAlign);
+            w.dataOffset = pos + 8;
+            return MFCC_OK;
+        }
+        pos += 8 + (size_t)sz + (sz & 1u);
+    }
+    return set_error("no data chunk"), MFCC_E_WAV;
+}
+
+int read_file(const char *path, std::vector<unsigned char> &out)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return set_error("open %s failed: %s", path, strerror(errno)), MFCC_E_OPEN;
+    fseek(fp, 0, SEEK_END);
+    const long n = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    const size_t got = out.empty() ? 0 : fread(out.data(), 1, out.size(), fp);
+    fclose(fp);
+    if (got != out.size()) return set_error("short read on %s", path), MFCC_E_OPEN;
+    return MFCC_OK;
+}
+
+} // namespace mfcc
+
+using namespace mfcc;
+
+extern "C" int MFCCWavInfo(const void *wavFile, size_t wavLen, int *channels, int *sampleRate,
+                           int *bytesPerSample, long *numSamples, size_t *dataOffset)
+{
+    WavInfo w;
+    const int rc = wav_parse(static_cast<const unsigned char *>(wavFile), wavLen, w);
+    if (rc) return rc;
+    if (channels) *channels = w.channels;
+    if (sampleRate) *sampleRate = w.sampleRate;
+    if (bytesPerSample) *bytesPerSample = w.bytesPerSample;
+    if (numSamples) *numSamples = w.numSamples;
+    if (dataOffset) *dataOffset = w.dataOffset;
+    return MFCC_OK;
+}
+
+extern "C" int MFCCWriteFeatures(const char *path, const double *data, long numFrames, int step,
+                                 int saveType)
+{
+    if (!path || (!data && numFrames > 0) || step <= 0 || numFrames < 0)
+        return set_error("bad argument to MFCCWriteFeatures"), MFCC_E_ARG;
+    const bool text = saveType == MFCC_SAVE_F || saveType == MFCC_SAVE_E;
+    FILE *fp = fopen(path, text ? "w" : "wb");
+    if (!fp) return set_error("open %s failed: %s", path, strerror(errno)), MFCC_E_WRITE;
+    const size_t n = (size_t)numFrames * (size_t)step;
+    bool ok = true;
+    if (text) {
+        // "%f\t" / "%e\t" per value, "\n" after every `step` values (main.c:276-285)
+        const char *fmt = saveType == MFCC_SAVE_F ? "%f\t" : "%e\t";
+        std::vector<char> buf;
+        buf.reserve(1 << 20);
+        char tmp[400];
+        for (size_t i = 0; i < n; ++i) {
+            const int len = snprintf(tmp, sizeof tmp, fmt, data[i]);
+            buf.insert(buf.end(), tmp, tmp + len);
+            if ((i + 1) % (size_t)step == 0) buf.push_back('\n');
+            if (buf.size() > (1 << 20) - 512) {
+                ok = ok && fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
+                buf.clear();
+            }
+        }
+        if (!buf.empty()) ok = ok && fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
+    } else {
+        if (saveType == MFCC_SAVE_N) {
+            // npy v1.0 header as create_npy_header<double> builds it (cnpy.hpp:235-264)
+            std::string dict = "{'descr': '<f8', 'fortran_order': False, 'shape': (";
+            dict += std::to_string(numFrames) + ", " + std::to_string(step) + "), }";
+            const int remainder = 16 - (int)((10 + dict.size()) % 16);
+            dict.append((size_t)remainder, ' ');
+            dict.back() = '\n';
+            unsigned char pre[10] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0, 0, 0};
+            pre[8] = (unsigned char)(dict.size() & 0xff);
+            pre[9] = (unsigned char)((dict.size() >> 8) & 0xff);
+            ok = ok && fwrite(pre, 1, 10, fp) == 10;
+            ok = ok && fwrite(dict.data(), 1, dict.size(), fp) == dict.size();
+        }
+        if (n) ok = ok && fwrite(data, sizeof(double), n, fp) == n;
+    }
+    if (fclose(fp) != 0) ok = false;
+    if (!ok) return set_error("write to %s failed", path), MFCC_E_WRITE;
+    return MFCC_OK;
+}
+
+// Integer-only generator: u <- u * 6364136223846793005 + 1442695040888963407 (mod 2^64);
+// sample = (((u >> 40) & 0xFFFF) + ((u >> 20) & 0xFFFF)) / 2 - 32768 (triangular pdf), shifted
+// left 8 for 24-bit, plus an integer-table tone at -12 dBFS.
+extern "C" int MFCCSynthPcm(void *dst, int channels, int ch, int bytesPerSample, int64_t numSamples,
+                            uint64_t seed, int sampleRate, int toneHz)
+{
+    if (!dst || channels < 1 || ch < 0 || ch >= channels || (bytesPerSample != 2 && bytesPerSample != 3))
+        return set_error("bad argument to MFCCSynthPcm"), MFCC_E_ARG;
+    // One period of a sine in 1/1024 turns, amplitude 8192 (-12 dBFS of 16-bit), built with
+    // integer arithmetic only: Bhaskara's approximation sin(x) ~ 16x(pi-x)/(5pi^2-4x(pi-x)).
+    static int16_t table[1024];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < 512; ++i) {
+            const int64_t x = i, p = 512; // half turn = 512 steps
+            const int64_t num = 16 * x * (p - x) * 8192, den = 5 * p * p - 4 * x * (p - x);
+            table[i] = (int16_t)(num / den);
+            table[i + 512] = (int16_t)(-(num / den));
+        }
+        init = true;
+    }
+    unsigned char *out = static_cast<unsigned char *>(dst);
+    const size_t stride = (size_t)channels * bytesPerSample;
+    uint64_t u = seed;
+    uint64_t phase = 0; // in 1/2^32 turns
+    const uint64_t dphase = toneHz > 0 ? (((uint64_t)toneHz << 32) / (uint64_t)sampleRate) : 0;
+    for (int64_t i = 0; i < numSamples; ++i) {
+        u = u * 6364136223846793005ull + 1442695040888963407ull;
+        int32_t v = (int32_t)((((u >> 40) & 0xFFFF) + ((u >> 20) & 0xFFFF)) >> 1) - 32768;
+        if (toneHz > 0) {
+            v = v / 2 + table[(phase >> 22) & 1023];
+            phase = (phase + dphase) & 0xFFFFFFFFull;
+        }
+        if (v > 32767) v = 32767;
+        if (v < -32768) v = -32768;
+        unsigned char *p = out + (size_t)i * stride + (size_t)ch * bytesPerSample;
+        if (bytesPerSample == 2) {
+            p[0] = (unsigned char)(v & 0xff);
+            p[1] = (unsigned char)((v >> 8) & 0xff);
+        } else {
+            const int32_t w = v * 256 + (int32_t)((u >> 12) & 0xff); // fill the low byte too
+            p[0] = (unsigned char)(w & 0xff);
+            p[1] = (unsigned char)((w >> 8) & 0xff);
+            p[2] = (unsigned char)((w >> 16) & 0xff);
+        }
+    }
+    return MFCC_OK;
+}

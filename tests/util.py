@@ -1,0 +1,103 @@
+"""Shared helpers of the test-suite: named option sets and the GPU-vs-oracle comparison."""
+import numpy as np
+
+# Option sets named after the five benchmark configurations (plus variants).
+CONFIGS = {
+    # 16 kHz mono 25 ms / 10 ms, 40-bin log-mel
+    "c2": dict(sampleRate=16000, lowpassfre=20, hipassfre=8000, preemphasise=0.97, wlen=400,
+               inc=160, vecNum=1, fbankFlag=1, bankNum=40),
+    # 16 kHz 13 MFCC + C0 + energy, deltas (delwin 2) + znorm
+    "c3": dict(sampleRate=16000, lowpassfre=64, hipassfre=8000, preemphasise=0.97, wlen=400,
+               inc=160, vecNum=1, fbankFlag=0, bankNum=26, MFCCNum=13, MFCC0thFlag=1, energyFlag=1,
+               regreOrder=3, delwin=2, znormFlag=1),
+    # 44.1 kHz stereo vecNum 2, 40 MFCC + ZCR / brightness / 8 sub-bands, 2048-point FFT
+    "c4": dict(sampleRate=44100, lowpassfre=10, hipassfre=22050, preemphasise=0.97, wlen=1764,
+               inc=882, vecNum=2, fbankFlag=0, bankNum=40, MFCCNum=40, zeroCrossingFlag=1,
+               brightFlag=1, subBandEFlag=8),
+    # the reference's example/config.ini verbatim (306 columns)
+    "c1a": dict(sampleRate=44100, lowpassfre=10, hipassfre=22050, preemphasise=0.0, wlen=1764,
+                inc=882, vecNum=2, fbankFlag=1, bankNum=40, MFCCNum=-1, energyFlag=1,
+                zeroCrossingFlag=1, brightFlag=1, subBandEFlag=8, regreOrder=3, delwin=9),
+    # README's 408-column variant: vecNum 4, regreOrder 2
+    "c1b": dict(sampleRate=44100, lowpassfre=10, hipassfre=22050, preemphasise=0.0, wlen=1764,
+                inc=882, vecNum=4, fbankFlag=1, bankNum=40, MFCCNum=-1, energyFlag=1,
+                zeroCrossingFlag=1, brightFlag=1, subBandEFlag=8, regreOrder=2, delwin=9),
+}
+CONFIGS["c5"] = dict(CONFIGS["c1a"], znormFlag=1)
+
+
+def oracle_cfg(ob, **kw):
+    return ob.make_config(**{k: v for k, v in kw.items()})
+
+
+def product_cfg(ma, precision=0, **kw):
+    return ma.make_config(precision=precision, **kw)
+
+
+def column_kinds(kw):
+    """Per static column of one vec: 'mel' (log-mel), 'cep', 'c0', 'energy', 'zc', 'bright',
+    'sub', 'fft'."""
+    fb = kw.get("fbankFlag", 1)
+    kinds = (["mel"] * kw["bankNum"]) if fb else (["cep"] * kw["MFCCNum"])
+    if not fb and kw.get("MFCC0thFlag", 0):
+        kinds.append("c0")
+    if kw.get("energyFlag", 0):
+        kinds.append("energy")
+    if kw.get("zeroCrossingFlag", 0):
+        kinds.append("zc")
+    if kw.get("brightFlag", 0):
+        kinds.append("bright")
+    kinds += ["sub"] * kw.get("subBandEFlag", 0)
+    kinds += ["fft"] * kw.get("fftLength", 0)
+    return kinds
+
+
+def assert_static_close(got, ref, kw, f64=False):
+    """Tolerances for the static block: log-mel / log-energy 1e-4 absolute; cepstra and C0 1e-5
+    relative to the largest cepstral magnitude of the matrix; ZCR exact; brightness / sub-band
+    fractions 1e-5 absolute; debug FFT magnitudes 1e-5 relative to the largest magnitude.
+    In f64 mode everything must agree to 1e-9 (relative to magnitude)."""
+    kinds = column_kinds(kw) * kw.get("vecNum", 1)
+    assert got.shape == ref.shape
+    n = len(kinds)
+    g, r = got[:, :n], ref[:, :n]
+    assert np.array_equal(np.isnan(g), np.isnan(r))
+    assert np.array_equal(np.isinf(g), np.isinf(r))
+    fin = np.isfinite(r)
+    g = np.where(fin, g, 0.0)
+    r = np.where(fin, r, 0.0)
+    kinds = np.array(kinds)
+    if f64:
+        scale = np.maximum(np.abs(r), 1.0)
+        assert np.max(np.abs(g - r) / scale, initial=0.0) < 1e-9
+        return
+    for kind, atol_of in (("mel", lambda x: 1e-4), ("energy", lambda x: 1e-4),
+                          ("cep", lambda x: 1e-5 * max(x, 1.0)), ("c0", lambda x: 1e-5 * max(x, 1.0)),
+                          ("zc", lambda x: 0.0), ("bright", lambda x: 1e-5), ("sub", lambda x: 1e-5),
+                          ("fft", lambda x: 1e-5 * max(x, 1.0))):
+        m = kinds == kind
+        if not m.any() or g.shape[0] == 0:
+            continue
+        if kind in ("cep", "c0"):
+            mx = float(np.max(np.abs(r[:, (kinds == "cep") | (kinds == "c0")])))
+        else:
+            mx = float(np.max(np.abs(r[:, m])))
+        err = float(np.max(np.abs(g[:, m] - r[:, m])))
+        assert err <= atol_of(mx), "%s: max error %g > %g" % (kind, err, atol_of(mx))
+
+
+def run_product_batch(ma, cfg, pcm_list, channels, bps, device=0):
+    """Runs the batch through the C ABI on the GPU; returns a list of float64 [T, step]."""
+    import torch
+    ctx = ma.Context(cfg, device)
+    buf, offs = ma.pack_utterances(pcm_list)
+    ns = np.array([len(p) // (channels * bps) for p in pcm_list], dtype=np.int64)
+    plan = ma.Plan(ctx, channels, bps, offs, ns)
+    dev = torch.from_numpy(buf).to("cuda:%d" % device)
+    out = plan.extract(dev)
+    torch.cuda.synchronize()
+    host = out.double().cpu().numpy()
+    res = [host[plan.row_offset(u):plan.row_offset(u) + plan.frames(u)] for u in range(len(ns))]
+    plan.close()
+    ctx.close()
+    return res
