@@ -46,6 +46,7 @@ struct MFCCPlan {
     int64_t totalRows = 0;
     int numTiles = 0, numChunks = 0;
     int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0;
+    int tabElems = 0, winPad = 0, fbkElems = 0, blocksPerCu = 1, numCus = 256;
     size_t ldsBytes = 0;
     UttDesc *dUtts = nullptr;
     int32_t *dTileUtt = nullptr, *dChunkUtt = nullptr;
@@ -151,40 +152,61 @@ extern "C" int MFCCContextTables(const MFCCContext *c, int *fftN, int *klo, int 
 // plans
 // ------------------------------------------------------------------------------------------
 
+// LDS geometry of the static-feature kernel for this plan: frames per tile, whether the window /
+// twiddle / split tables get an LDS copy, and how many workgroups fit a CU.
 static int choose_tile(MFCCPlan *p)
 {
     const MFCCContext *c = p->ctx;
     const int V = c->cfg.vecNum, log2nc = c->tab.log2nc, prec = c->cfg.precision;
+    const int nc = c->tab.nc, P = c->cfg.bankNum;
     const int groups = front_groups(log2nc), zPitch = front_zpitch(log2nc);
     const size_t el = prec == MFCC_PREC_F64 ? 8 : 4;
     const int bpi = p->channels * p->bps;
     const int base = (groups + V - 1) / V;
-    auto geometry = [&](int ft, int &rowPitch, int &rawOrZ) {
+    const size_t kLds = 160 * 1024;
+    const int wavesCap = front_waves_limit(prec, log2nc); // workgroups per CU the registers allow
+    p->winPad = (c->cfg.wlen + 3) & ~3;
+    p->fbkElems = P <= nc ? 0 : ((groups * P + 3) & ~3);
+    const size_t tabElems = (size_t)p->winPad + 2 * (size_t)nc + (size_t)std::max(nc, 2);
+    auto geometry = [&](int ft, bool tabLds, int &rowPitch, int &rawOrZ) {
         const long ninst = (long)(ft - 1) * c->cfg.inc + c->cfg.wlen + 1;
         rowPitch = (int)((ninst + 3) & ~3L);
         const size_t rawBytes = (size_t)ninst * bpi + 48;
-        const size_t zElems = (size_t)groups * zPitch;
-        size_t n = std::max(zElems, (rawBytes + el - 1) / el);
-        n = (n + 3) & ~(size_t)3;
-        rawOrZ = (int)n;
-        return front_lds_bytes(prec, log2nc, V, rowPitch, zPitch, rawOrZ, ft, c->vSize, c->cfg.bankNum);
+        size_t n = std::max((size_t)groups * zPitch, (rawBytes + el - 1) / el);
+        rawOrZ = (int)((n + 3) & ~(size_t)3);
+        const size_t feat = ((size_t)ft * c->vSize + 3) & ~(size_t)3;
+        const size_t elems = (tabLds ? tabElems : 0) + (size_t)V * rowPitch + rawOrZ + feat +
+                             p->fbkElems + 8;
+        return elems * el;
     };
-    const size_t kPreferred = 64 * 1024, kMax = 160 * 1024;
-    int best = 0;
-    for (int m = 4; m >= 1 && !best; --m) {
+    // Prefer the occupancy the registers allow, then LDS tables, then longer tiles.
+    int bestFt = 0, bestBlocks = 0;
+    bool bestTab = false;
+    for (int blocks = wavesCap; blocks >= 1 && !bestFt; --blocks)
+        for (int tab = 1; tab >= 0 && !bestFt; --tab)
+            for (int m = 2; m >= 1 && !bestFt; --m) {
+                int rp, rz;
+                if (geometry(base * m, tab != 0, rp, rz) * blocks <= kLds) {
+                    bestFt = base * m;
+                    bestTab = tab != 0;
+                    bestBlocks = blocks;
+                }
+            }
+    for (int ft = base - 1; ft >= 1 && !bestFt; --ft) {
         int rp, rz;
-        if (geometry(base * m, rp, rz) <= kPreferred) best = base * m;
+        if (geometry(ft, false, rp, rz) <= kLds) {
+            bestFt = ft;
+            bestBlocks = 1;
+        }
     }
-    for (int ft = base; ft >= 1 && !best; --ft) {
-        int rp, rz;
-        if (geometry(ft, rp, rz) <= kMax) best = ft;
-    }
-    if (!best)
+    if (!bestFt)
         return set_error("wlen %d / fftN %d needs more than 160 KiB of LDS per workgroup",
                          c->cfg.wlen, c->tab.fftN),
                MFCC_E_CONFIG;
-    p->framesPerTile = best;
-    p->ldsBytes = geometry(best, p->rowPitch, p->rawOrZElems);
+    p->framesPerTile = bestFt;
+    p->tabElems = bestTab ? (int)tabElems : 0;
+    p->blocksPerCu = bestBlocks;
+    p->ldsBytes = geometry(bestFt, bestTab, p->rowPitch, p->rawOrZElems);
     return MFCC_OK;
 }
 
@@ -216,6 +238,11 @@ static int finish_plan(MFCCPlan *p)
     p->numTiles = (int)tiles;
     p->numChunks = (int)chunks;
     HIP_TRY(hipSetDevice(c->device));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0)
+            p->numCus = cus;
+    }
     const size_t nu = std::max<size_t>(p->utts.size(), 1);
     HIP_TRY(hipMalloc((void **)&p->dUtts, nu * sizeof(UttDesc)));
     if (!p->utts.empty())
@@ -423,9 +450,13 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.chanRange = c->dChanRange;
     a.dct = static_cast<const T *>(c->dDct);
     a.rowPitch = p->rowPitch;
-    a.zPitch = front_zpitch(c->tab.log2nc);
     a.rawOrZElems = p->rawOrZElems;
-    const int rc = launch_front(c->cfg.precision, c->tab.log2nc, &a, p->numTiles, p->ldsBytes, stream);
+    a.tabElems = p->tabElems;
+    a.winPad = p->winPad;
+    a.fbkElems = p->fbkElems;
+    // persistent workgroups: as many as stay resident, each walks tiles with a grid stride
+    const int blocks = (int)std::min<int64_t>(p->numTiles, (int64_t)p->numCus * p->blocksPerCu);
+    const int rc = launch_front(c->cfg.precision, c->tab.log2nc, &a, blocks, p->ldsBytes, stream);
     if (rc) return set_error("static-feature kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;
 }

@@ -46,8 +46,10 @@ struct FrontArgs {
     const int32_t *chanRange; // P x 4: [hiBegin, hiEnd) bins taken with (1 - loWt), [loBegin, loEnd) with loWt
     const T *dct;          // P x M, k-major: cos(pi (j+1) (k + 0.5) / P)
     int rowPitch;          // elements per derived row in LDS
-    int zPitch;            // elements per frame-group work area in LDS
     int rawOrZElems;       // elements reserved for max(raw PCM bytes, all work areas)
+    int tabElems;          // elements of the LDS copy of window | twiddles | split (0: read from HBM/L2)
+    int winPad;            // elements reserved for the window inside that copy
+    int fbkElems;          // elements of the separate log-mel area (0: kept behind the power values)
 };
 
 template <typename T>
@@ -72,12 +74,11 @@ struct StatArgs {
     double *stats;   // numUtts x 2*step : mean, 1/std  (batch plans)  or  shard sums (2*step+1)
 };
 
-int launch_front(int precision, int log2nc, const void *args, int numTiles, size_t ldsBytes,
+int launch_front(int precision, int log2nc, const void *args, int numBlocks, size_t ldsBytes,
                  void *stream);
-size_t front_lds_bytes(int precision, int log2nc, int V, int rowPitch, int zPitch, int rawOrZElems,
-                       int framesPerTile, int vSize, int P);
 int front_groups(int log2nc);   // frame groups per workgroup
 int front_zpitch(int log2nc);   // elements per work area
+int front_waves_limit(int precision, int log2nc); // waves per SIMD the kernel is compiled for
 int launch_regress(int precision, const void *args, int numTiles, void *stream);
 int launch_colstats(int precision, const void *args, int numChunks, void *stream);
 int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream);

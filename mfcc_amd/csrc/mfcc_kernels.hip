@@ -20,12 +20,31 @@ struct Geo {
     static constexpr int G = NC >= 16 ? (NC / 16 > kBlock ? kBlock : NC / 16) : 1; // lanes per frame
     static constexpr int PPL = NC / G;                            // complex points per lane
     static constexpr int GROUPS = kBlock / G;                     // frames in flight per workgroup
-    static constexpr int ZPITCH = 2 * NC + 2;                     // elements per work area
+    // work area: nc complex points, one pad point after every 16 (so that the 16x16 exchange
+    // between two radix-16 stages is free of LDS bank conflicts), rounded to a multiple of 4
+    static constexpr int ZPITCH = ((2 * (NC + NC / 16) + 2) + 3) & ~3;
 };
+
+// index of complex point i inside a work area
+__device__ __forceinline__ int zpad(int i) { return i + (i >> 4); }
 
 // ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
+
+// Orders the LDS traffic of the lanes that share one frame.  Up to 64 lanes sit in one wave,
+// whose LDS instructions execute in program order, so only the compiler has to be held back.
+template <int G>
+__device__ __forceinline__ void group_sync()
+{
+    if constexpr (G <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
 
 template <typename V, int G>
 __device__ __forceinline__ V group_sum(V v, V *scratch, int tid)
@@ -90,7 +109,7 @@ __device__ __forceinline__ double tsqrt<double>(double x) { return sqrt(x); }
 
 template <typename T, int LOG2NC, int LOGNS>
 __device__ __forceinline__ void fft_stages(cpx<T> (&v)[Geo<LOG2NC>::PPL], cpx<T> *Z, int l,
-                                           const T *__restrict__ tw)
+                                           const T *tw)
 {
     using GEO = Geo<LOG2NC>;
     constexpr int NC = GEO::NC, G = GEO::G, PPL = GEO::PPL;
@@ -101,7 +120,7 @@ __device__ __forceinline__ void fft_stages(cpx<T> (&v)[Geo<LOG2NC>::PPL], cpx<T>
         for (int b = 0; b < NB; ++b) {
             const int j = l + G * b;
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[b * R + r] = Z[j + r * STRIDE];
+            for (int r = 0; r < R; ++r) v[b * R + r] = Z[zpad(j + r * STRIDE)];
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -114,7 +133,7 @@ __device__ __forceinline__ void fft_stages(cpx<T> (&v)[Geo<LOG2NC>::PPL], cpx<T>
                 v[b * R + r] = cmul(v[b * R + r], w);
             }
         }
-        __syncthreads(); // every read of Z is done before any lane overwrites it
+        group_sync<G>(); // every read of Z is done before any lane overwrites it
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) Radix<T, R>::run(&v[b * R]);
@@ -123,34 +142,56 @@ __device__ __forceinline__ void fft_stages(cpx<T> (&v)[Geo<LOG2NC>::PPL], cpx<T>
         const int j = l + G * b;
         const int o = ((j >> LOGNS) << (LOGNS + RB)) + (j & (NS - 1));
 #pragma unroll
-        for (int r = 0; r < R; ++r) Z[o + r * NS] = v[b * R + r];
+        for (int r = 0; r < R; ++r) Z[zpad(o + r * NS)] = v[b * R + r];
     }
-    __syncthreads();
+    group_sync<G>();
     if constexpr (LOGNS + RB < LOG2NC) fft_stages<T, LOG2NC, LOGNS + RB>(v, Z, l, tw);
 }
 
+// Registers the compiler may use per lane, as waves per SIMD it has to leave room for.
+template <typename T, int LOG2NC>
+constexpr int front_waves_per_simd()
+{
+    return sizeof(T) == 4 ? (LOG2NC <= 9 ? 3 : (LOG2NC <= 11 ? 2 : 1)) : (LOG2NC <= 7 ? 2 : 1);
+}
+
 // ------------------------------------------------------------------------------------------
-// Fused static-feature kernel
+// Fused static-feature kernel.  TLDS: window / twiddle / split tables are staged in LDS.
 // ------------------------------------------------------------------------------------------
 
-template <typename T, int LOG2NC>
-__global__ __launch_bounds__(kBlock) void k_front(const FrontArgs<T> a)
+template <typename T, int LOG2NC, bool TLDS>
+__global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k_front(
+    const FrontArgs<T> a)
 {
     using GEO = Geo<LOG2NC>;
     constexpr int NC = GEO::NC, G = GEO::G, PPL = GEO::PPL, GROUPS = GEO::GROUPS;
     constexpr int R0B = LOG2NC < 4 ? LOG2NC : 4, R0 = 1 << R0B; // radix of the first stage
+    constexpr int NPAIR = PPL / 2 > 0 ? PPL / 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *rows = reinterpret_cast<T *>(smem);          // V x rowPitch pre-emphasised samples
+    T *ldsTab = reinterpret_cast<T *>(smem);        // [window | twiddles | split factors] if TLDS
+    T *rows = ldsTab + a.tabElems;                  // V x rowPitch pre-emphasised samples
     T *zbuf = rows + a.V * a.rowPitch;              // GROUPS work areas; raw PCM bytes alias it
     T *feat = zbuf + a.rawOrZElems;                 // framesPerTile x vSize static features
-    T *fbk = feat + a.framesPerTile * a.vSize;      // GROUPS x P log-mel values
-    T *red = fbk + GROUPS * a.P;                    // 8 elements for cross-wave sums
+    T *fbkSep = feat + a.framesPerTile * a.vSize;   // GROUPS x P log-mel values (if not in Z)
+    T *red = fbkSep + a.fbkElems;                   // 8 elements for cross-wave sums
     unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
 
     const int tid = threadIdx.x;
     const int l = tid & (G - 1), grp = tid / G;
     const int bpi = a.channels * a.bps;
+
+    const T *win = a.window, *tw = a.tw, *split = a.splitTw;
+    if constexpr (TLDS) {
+        T *w = ldsTab, *t = w + a.winPad, *sp = t + 2 * NC;
+        for (int i = tid; i < a.wlen; i += kBlock) w[i] = a.window[i];
+        for (int i = tid; i < 2 * NC; i += kBlock) t[i] = a.tw[i];
+        for (int i = tid; i < (NC > 1 ? NC : 2); i += kBlock) sp[i] = a.splitTw[i];
+        win = w;
+        tw = t;
+        split = sp;
+        __syncthreads();
+    }
 
     for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
         const int u = a.tileUtt[tile];
@@ -216,8 +257,10 @@ __global__ __launch_bounds__(kBlock) void k_front(const FrontArgs<T> a)
             const bool active = item < nItems;
             const int fr = active ? item / a.V : 0, vv = active ? item - fr * a.V : 0;
             const T *x = rows + vv * a.rowPitch + fr * a.inc;
-            cpx<T> *Z = reinterpret_cast<cpx<T> *>(zbuf + grp * GEO::ZPITCH);
-            T *Pw = zbuf + grp * GEO::ZPITCH;
+            T *Zt = zbuf + grp * GEO::ZPITCH;
+            cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
+            T *Pw = Zt;                                   // power spectrum, nc values
+            T *fbk = a.fbkElems ? fbkSep + grp * a.P : Zt + NC; // log-mel values of this frame
             T *fo = feat + item * a.D;
 
             // ---- window, frame energy, zero crossings, first FFT stage input (Ham main.c:229,
@@ -239,8 +282,8 @@ __global__ __launch_bounds__(kBlock) void k_front(const FrontArgs<T> a)
                         zc += ((x0 < 0 && x1 > 0) || (x0 > 0 && x1 < 0)) ? 1 : 0;
                         zc += ((x1 < 0 && x2 > 0) || (x1 > 0 && x2 < 0)) ? 1 : 0;
                     }
-                    const T w0 = s0 < a.wlen ? a.window[s0] : (T)0;
-                    const T w1 = s1 < a.wlen ? a.window[s1] : (T)0;
+                    const T w0 = s0 < a.wlen ? win[s0] : (T)0;
+                    const T w1 = s1 < a.wlen ? win[s1] : (T)0;
                     x0 *= w0;
                     x1 *= w1;
                     te += x0 * x0 + x1 * x1;
@@ -251,21 +294,21 @@ __global__ __launch_bounds__(kBlock) void k_front(const FrontArgs<T> a)
             if (a.zcFlag) zc = group_sum<int, G>(zc, reinterpret_cast<int *>(red), tid);
 
             // ---- nc-point complex FFT of z[n] = x[2n] + i x[2n+1]   (Realft mfcc.c:262-270)
-            fft_stages<T, LOG2NC, 0>(v, Z, l, a.tw);
+            fft_stages<T, LOG2NC, 0>(v, Z, l, tw);
 
             // ---- real-FFT split and power  (mfcc.c:274-290, ek of mfcc.c:153-155)
             // X[k] = E + w O, X[nc-k] = conj(E - w O), w = exp(-i pi k / nc); only |X|^2 is kept.
-            T pa[PPL / 2 > 0 ? PPL / 2 : 1], pb[PPL / 2 > 0 ? PPL / 2 : 1];
+            T pa[NPAIR], pb[NPAIR];
 #pragma unroll
-            for (int q = 0; q < (PPL / 2 > 0 ? PPL / 2 : 1); ++q) {
+            for (int q = 0; q < NPAIR; ++q) {
                 const int k = l + G * q;
                 if (k == 0) {
-                    const cpx<T> z0 = Z[0], zh = Z[NC / 2];
+                    const cpx<T> z0 = Z[0], zh = Z[zpad(NC / 2)];
                     pa[q] = (z0.x + z0.y) * (z0.x + z0.y);
                     pb[q] = NC > 1 ? zh.x * zh.x + zh.y * zh.y : (T)0;
                 } else {
-                    const cpx<T> za = Z[k], zb = Z[NC - k];
-                    const T c = a.splitTw[2 * k], s = a.splitTw[2 * k + 1];
+                    const cpx<T> za = Z[zpad(k)], zb = Z[zpad(NC - k)];
+                    const T c = split[2 * k], s = split[2 * k + 1];
                     const T ex = (T)0.5 * (za.x + zb.x), ey = (T)0.5 * (za.y - zb.y);
                     const T ox = (T)0.5 * (za.y + zb.y), oy = (T)-0.5 * (za.x - zb.x);
                     const T wx = c * ox + s * oy, wy = c * oy - s * ox;
@@ -273,9 +316,9 @@ __global__ __launch_bounds__(kBlock) void k_front(const FrontArgs<T> a)
                     pb[q] = (ex - wx) * (ex - wx) + (ey - wy) * (ey - wy);
                 }
             }
-            __syncthreads();
+            group_sync<G>();
 #pragma unroll
-            for (int q = 0; q < (PPL / 2 > 0 ? PPL / 2 : 1); ++q) {
+            for (int q = 0; q < NPAIR; ++q) {
                 const int k = l + G * q;
                 if (k == 0) {
                     Pw[0] = pa[q];
@@ -285,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void k_front(const FrontArgs<T> a)
                     Pw[NC - k] = pb[q];
                 }
             }
-            __syncthreads();
+            group_sync<G>();
 
             // ---- brightness and sub-band energies (call sites main.c:235-236)
             if (a.brightFlag || a.S > 0) {
@@ -324,39 +367,37 @@ __global__ __launch_bounds__(kBlock) void k_front(const FrontArgs<T> a)
             }
 
             // ---- mel filterbank, gather form of the two-tap scatter of mfcc.c:152-163, then
-            //      log(max(., 1))  (mfcc.c:171-176)
-            if (active) {
-                for (int ch = l; ch < a.P; ch += G) {
-                    const int4 rg = reinterpret_cast<const int4 *>(a.chanRange)[ch];
-                    T acc = 0;
-                    for (int k = rg.x; k < rg.y; ++k) {
-                        const T pv = Pw[k];
-                        acc += pv - a.loWt[k] * pv;
-                    }
-                    for (int k = rg.z; k < rg.w; ++k) acc += a.loWt[k] * Pw[k];
-                    const T lv = tlog<T>(acc < (T)1 ? (T)1 : acc);
-                    fbk[grp * a.P + ch] = lv;
-                    if (a.fbankFlag) fo[ch] = lv;
+            //      log(max(., 1))  (mfcc.c:171-176).  fbk sits behind the nc power values.
+            for (int ch = l; ch < a.P; ch += G) {
+                const int4 rg = reinterpret_cast<const int4 *>(a.chanRange)[ch];
+                T acc = 0;
+                for (int k = rg.x; k < rg.y; ++k) {
+                    const T pv = Pw[k];
+                    acc += pv - a.loWt[k] * pv;
                 }
+                for (int k = rg.z; k < rg.w; ++k) acc += a.loWt[k] * Pw[k];
+                const T lv = tlog<T>(acc < (T)1 ? (T)1 : acc);
+                fbk[ch] = lv;
+                if (active && a.fbankFlag) fo[ch] = lv;
             }
-            __syncthreads();
+            group_sync<G>();
 
             // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208)
             if (active && !a.fbankFlag) {
-                const T *fb = fbk + grp * a.P;
                 for (int j = l; j < a.M + a.c0Flag; j += G) {
                     T acc = 0;
                     if (j < a.M) {
-                        for (int k = 0; k < a.P; ++k) acc += fb[k] * a.dct[k * a.M + j];
+                        for (int k = 0; k < a.P; ++k) acc += fbk[k] * a.dct[k * a.M + j];
                     } else {
-                        for (int k = 0; k < a.P; ++k) acc += fb[k];
+                        for (int k = 0; k < a.P; ++k) acc += fbk[k];
                     }
                     fo[j] = acc * a.mfnorm;
                 }
             }
-            // the next round overwrites the work areas and fbk: all lanes must be done reading
-            __syncthreads();
+            // the next round overwrites the work area: every lane of the frame is done with it
+            group_sync<G>();
         }
+        __syncthreads();
 
         // ---- tile rows -> HBM (static block of every row; delta slots are written later)
         const long long row0 = ud.outRow + f0;
@@ -364,7 +405,6 @@ __global__ __launch_bounds__(kBlock) void k_front(const FrontArgs<T> a)
             const int r = i / a.vSize, c = i - r * a.vSize;
             a.out[(row0 + r) * a.step + c] = feat[i];
         }
-        __syncthreads();
     }
 }
 
@@ -608,18 +648,18 @@ __global__ void k_uttmeans(UttDesc *utts, int numUtts, const unsigned long long 
         if (e_ != hipSuccess) return (int)e_; \
     } while (0)
 
-template <typename T, int L>
+template <typename T, int L, bool TLDS>
 static int launch_front_t(const FrontArgs<T> &a, int numBlocks, size_t lds, hipStream_t st)
 {
     static bool attrSet[16] = {};
     int dev = 0;
     MFCC_HIP_OK(hipGetDevice(&dev));
     if (dev < 16 && !attrSet[dev]) {
-        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L>),
+        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, TLDS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attrSet[dev] = true;
     }
-    hipLaunchKernelGGL((k_front<T, L>), dim3(numBlocks), dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((k_front<T, L, TLDS>), dim3(numBlocks), dim3(kBlock), lds, st, a);
     return (int)hipGetLastError();
 }
 
@@ -627,9 +667,12 @@ template <typename T>
 static int launch_front_p(int log2nc, const void *args, int numBlocks, size_t lds, hipStream_t st)
 {
     const FrontArgs<T> &a = *static_cast<const FrontArgs<T> *>(args);
+    const bool tl = a.tabElems > 0;
     switch (log2nc) {
-#define MFCC_CASE(L) \
-    case L: return launch_front_t<T, L>(a, numBlocks, lds, st);
+#define MFCC_CASE(L)                                                         \
+    case L:                                                                  \
+        return tl ? launch_front_t<T, L, true>(a, numBlocks, lds, st)        \
+                  : launch_front_t<T, L, false>(a, numBlocks, lds, st);
         MFCC_CASE(1) MFCC_CASE(2) MFCC_CASE(3) MFCC_CASE(4) MFCC_CASE(5) MFCC_CASE(6) MFCC_CASE(7)
         MFCC_CASE(8) MFCC_CASE(9) MFCC_CASE(10) MFCC_CASE(11) MFCC_CASE(12) MFCC_CASE(13)
 #undef MFCC_CASE
@@ -637,13 +680,13 @@ static int launch_front_p(int log2nc, const void *args, int numBlocks, size_t ld
     }
 }
 
-int launch_front(int precision, int log2nc, const void *args, int numTiles, size_t ldsBytes,
+int launch_front(int precision, int log2nc, const void *args, int numBlocks, size_t ldsBytes,
                  void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (numTiles <= 0) return 0;
-    return precision == 1 ? launch_front_p<double>(log2nc, args, numTiles, ldsBytes, st)
-                          : launch_front_p<float>(log2nc, args, numTiles, ldsBytes, st);
+    if (numBlocks <= 0) return 0;
+    return precision == 1 ? launch_front_p<double>(log2nc, args, numBlocks, ldsBytes, st)
+                          : launch_front_p<float>(log2nc, args, numBlocks, ldsBytes, st);
 }
 
 int front_groups(int log2nc)
@@ -653,16 +696,15 @@ int front_groups(int log2nc)
     return kBlock / g;
 }
 
-int front_zpitch(int log2nc) { return 2 * (1 << log2nc) + 2; }
-
-size_t front_lds_bytes(int precision, int log2nc, int V, int rowPitch, int zPitch, int rawOrZElems,
-                       int framesPerTile, int vSize, int P)
+int front_zpitch(int log2nc)
 {
-    (void)zPitch;
-    const size_t el = precision == 1 ? 8 : 4;
-    const size_t n = (size_t)V * rowPitch + rawOrZElems + (size_t)framesPerTile * vSize +
-                     (size_t)front_groups(log2nc) * P + 8;
-    return n * el;
+    const int nc = 1 << log2nc;
+    return ((2 * (nc + nc / 16) + 2) + 3) & ~3;
+}
+
+int front_waves_limit(int precision, int log2nc)
+{
+    return precision == 1 ? (log2nc <= 7 ? 2 : 1) : (log2nc <= 9 ? 3 : (log2nc <= 11 ? 2 : 1));
 }
 
 int launch_regress(int precision, const void *args, int numTiles, void *stream)
