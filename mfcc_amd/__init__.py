@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfcc_amd.so")
+# MFCC_AMD_LIB lets the profiling tools load a diagnostic build of the same library
+LIB_PATH = os.environ.get("MFCC_AMD_LIB") or os.path.join(_HERE, "libmfcc_amd.so")
 
 MAX_PATH = 600
 SAVE_F, SAVE_E, SAVE_N, SAVE_B = 0, 1, 2, 3

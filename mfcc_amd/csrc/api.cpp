@@ -46,7 +46,8 @@ struct MFCCPlan {
     int64_t totalRows = 0;
     int numTiles = 0, numChunks = 0;
     int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0;
-    int tabElems = 0, winPad = 0, fbkElems = 0, blocksPerCu = 1, numCus = 256;
+    int tabElems = 0, winPad = 0, featElems = 0, fbkElems = 0, rowTail = 0;
+    int blocksPerCu = 1, numCus = 256;
     size_t ldsBytes = 0;
     UttDesc *dUtts = nullptr;
     int32_t *dTileUtt = nullptr, *dChunkUtt = nullptr;
@@ -102,7 +103,11 @@ extern "C" int MFCCContextCreate(const MFCCConfig *cfgIn, int device, MFCCContex
     c->vSize = c->D * cfg.vecNum;
     c->step = c->vSize * cfg.regreOrder;
     const int p = cfg.precision;
-    if ((rc = upload_tab(p, c->tab.window, &c->dWindow))) return rc;
+    {
+        std::vector<double> padded(c->tab.window);
+        padded.resize((size_t)c->tab.fftN + 8, 0.0);
+        if ((rc = upload_tab(p, padded, &c->dWindow))) return rc;
+    }
     if ((rc = upload_tab(p, c->tab.tw, &c->dTw))) return rc;
     if ((rc = upload_tab(p, c->tab.splitTw, &c->dSplitTw))) return rc;
     if ((rc = upload_tab(p, c->tab.loWt, &c->dLoWt))) return rc;
@@ -164,13 +169,16 @@ static int choose_tile(MFCCPlan *p)
     const int bpi = p->channels * p->bps;
     const int base = (groups + V - 1) / V;
     const size_t kLds = 160 * 1024;
+    const int rowTail = c->tab.fftN - c->cfg.wlen + 2; // zero-filled, so frame loads need no bounds test
+    p->rowTail = rowTail;
     const int wavesCap = front_waves_limit(prec, log2nc); // workgroups per CU the registers allow
-    p->winPad = (c->cfg.wlen + 3) & ~3;
-    p->fbkElems = P <= nc ? 0 : ((groups * P + 3) & ~3);
-    const size_t tabElems = (size_t)p->winPad + 2 * (size_t)nc + (size_t)std::max(nc, 2);
+    p->winPad = (c->tab.fftN + 2 + 3) & ~3; // window values, then zeros up to fftN + 2
+    p->fbkElems = c->cfg.fbankFlag ? 0 : ((groups * P + 3) & ~3);
+    const size_t tabElems = (((size_t)p->winPad + 2 * (size_t)nc + (size_t)std::max(nc, 2) + (size_t)nc +
+                              4 * (size_t)P) + 3) & ~(size_t)3;
     auto geometry = [&](int ft, bool tabLds, int &rowPitch, int &rawOrZ) {
         const long ninst = (long)(ft - 1) * c->cfg.inc + c->cfg.wlen + 1;
-        rowPitch = (int)((ninst + 3) & ~3L);
+        rowPitch = (int)((ninst + rowTail + 3) & ~3L);
         const size_t rawBytes = (size_t)ninst * bpi + 48;
         size_t n = std::max((size_t)groups * zPitch, (rawBytes + el - 1) / el);
         rawOrZ = (int)((n + 3) & ~(size_t)3);
@@ -186,17 +194,28 @@ static int choose_tile(MFCCPlan *p)
         for (int tab = 1; tab >= 0 && !bestFt; --tab)
             for (int m = 2; m >= 1 && !bestFt; --m) {
                 int rp, rz;
-                if (geometry(base * m, tab != 0, rp, rz) * blocks <= kLds) {
+                // Measured on MI355X: three 54,208-byte workgroups are not co-resident on a CU
+                // while three 49,072-byte ones are, so budget in 4 KiB steps.
+                const size_t need = (geometry(base * m, tab != 0, rp, rz) + 4095) & ~(size_t)4095;
+                if (need * blocks <= kLds) {
                     bestFt = base * m;
                     bestTab = tab != 0;
                     bestBlocks = blocks;
                 }
             }
-    for (int ft = base - 1; ft >= 1 && !bestFt; --ft) {
+    for (int ft = base; ft >= 1 && !bestFt; --ft) {
         int rp, rz;
         if (geometry(ft, false, rp, rz) <= kLds) {
             bestFt = ft;
             bestBlocks = 1;
+        }
+    }
+    if (const char *e = getenv("MFCC_TILE")) { // tuning aid: "<framesPerTile>,<tablesInLds>,<workgroupsPerCu>"
+        int ft = 0, tab = 0, blocks = 0;
+        if (sscanf(e, "%d,%d,%d", &ft, &tab, &blocks) == 3 && ft > 0 && blocks > 0) {
+            bestFt = ft;
+            bestTab = tab != 0;
+            bestBlocks = blocks;
         }
     }
     if (!bestFt)
@@ -207,6 +226,14 @@ static int choose_tile(MFCCPlan *p)
     p->tabElems = bestTab ? (int)tabElems : 0;
     p->blocksPerCu = bestBlocks;
     p->ldsBytes = geometry(bestFt, bestTab, p->rowPitch, p->rawOrZElems);
+    p->featElems = (int)(((size_t)bestFt * c->vSize + 3) & ~(size_t)3);
+    const int occ = front_occupancy(prec, log2nc, bestTab, p->ldsBytes);
+    if (getenv("MFCC_DEBUG"))
+        fprintf(stderr, "mfcc plan: framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
+                bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
+    if (occ > 0 && occ < p->blocksPerCu) p->blocksPerCu = occ;
+    if (const char *e = getenv("MFCC_BLOCKS_PER_CU")) // tuning aid: resident workgroups per CU
+        if (atoi(e) > 0) p->blocksPerCu = atoi(e);
     return MFCC_OK;
 }
 
@@ -450,10 +477,33 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.chanRange = c->dChanRange;
     a.dct = static_cast<const T *>(c->dDct);
     a.rowPitch = p->rowPitch;
+    a.rowTail = p->rowTail;
     a.rawOrZElems = p->rawOrZElems;
     a.tabElems = p->tabElems;
     a.winPad = p->winPad;
+    a.featElems = p->featElems;
     a.fbkElems = p->fbkElems;
+    a.stamps = nullptr;
+#ifdef MFCC_STAMPS
+    {
+        static unsigned long long *dStamps = nullptr;
+        if (!dStamps) {
+            HIP_TRY(hipMalloc((void **)&dStamps, 12 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(dStamps, 0, 12 * sizeof(unsigned long long)));
+        }
+        if (getenv("MFCC_STAMPS_DUMP")) {
+            unsigned long long h[12];
+            HIP_TRY(hipMemcpy(h, dStamps, sizeof h, hipMemcpyDeviceToHost));
+            unsigned long long tot = 0;
+            for (int i = 0; i < 12; ++i) tot += h[i];
+            fprintf(stderr, "mfcc stamps (cycle shares of all earlier launches):");
+            for (int i = 0; i < 12; ++i) fprintf(stderr, " [%d] %.1f%%", i, tot ? 100.0 * h[i] / tot : 0.0);
+            fprintf(stderr, "  total %llu\n", tot);
+            HIP_TRY(hipMemset(dStamps, 0, 12 * sizeof(unsigned long long)));
+        }
+        a.stamps = dStamps;
+    }
+#endif
     // persistent workgroups: as many as stay resident, each walks tiles with a grid stride
     const int blocks = (int)std::min<int64_t>(p->numTiles, (int64_t)p->numCus * p->blocksPerCu);
     const int rc = launch_front(c->cfg.precision, c->tab.log2nc, &a, blocks, p->ldsBytes, stream);

@@ -39,17 +39,20 @@ struct FrontArgs {
     int c0Flag, energyFlag, zcFlag, brightFlag, S, fftLength, fbankFlag;
     double preK;
     T mfnorm;
-    const T *window;       // wlen
+    const T *window;       // wlen values, zero-padded to fftN + 8
     const T *tw;           // nc complex (cos, -sin)(2 pi m / nc), interleaved
     const T *splitTw;      // nc/2 complex (cos, sin)(pi a / nc), interleaved
     const T *loWt;         // nc
     const int32_t *chanRange; // P x 4: [hiBegin, hiEnd) bins taken with (1 - loWt), [loBegin, loEnd) with loWt
     const T *dct;          // P x M, k-major: cos(pi (j+1) (k + 0.5) / P)
     int rowPitch;          // elements per derived row in LDS
+    int rowTail;           // elements zero-filled behind the last sample of a tile (>= fftN - wlen + 1)
     int rawOrZElems;       // elements reserved for max(raw PCM bytes, all work areas)
-    int tabElems;          // elements of the LDS copy of window | twiddles | split (0: read from HBM/L2)
+    int tabElems;          // elements of the LDS copy of the tables (0: tables are read through L1/L2)
     int winPad;            // elements reserved for the window inside that copy
-    int fbkElems;          // elements of the separate log-mel area (0: kept behind the power values)
+    int featElems;         // elements of the static-feature staging area (framesPerTile x vSize, padded)
+    int fbkElems;          // elements of the log-mel area, GROUPS x P (0 in filterbank mode)
+    unsigned long long *stamps; // diagnostic builds only: 12 per-phase cycle sums (else NULL)
 };
 
 template <typename T>
@@ -79,6 +82,7 @@ int launch_front(int precision, int log2nc, const void *args, int numBlocks, siz
 int front_groups(int log2nc);   // frame groups per workgroup
 int front_zpitch(int log2nc);   // elements per work area
 int front_waves_limit(int precision, int log2nc); // waves per SIMD the kernel is compiled for
+int front_occupancy(int precision, int log2nc, bool tabLds, size_t ldsBytes);
 int launch_regress(int precision, const void *args, int numTiles, void *stream);
 int launch_colstats(int precision, const void *args, int numChunks, void *stream);
 int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream);

@@ -9,6 +9,8 @@
 // pair to a group of G = nc/16 lanes that hold 16 complex points each in registers.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "fft_regs.h"
 #include "mfcc_dev.h"
 
@@ -22,7 +24,7 @@ struct Geo {
     static constexpr int GROUPS = kBlock / G;                     // frames in flight per workgroup
     // work area: nc complex points, one pad point after every 16 (so that the 16x16 exchange
     // between two radix-16 stages is free of LDS bank conflicts), rounded to a multiple of 4
-    static constexpr int ZPITCH = ((2 * (NC + NC / 16) + 2) + 3) & ~3;
+    static constexpr int ZPITCH = (2 * (NC + NC / 16) + 3) & ~3;
 };
 
 // index of complex point i inside a work area
@@ -148,6 +150,105 @@ __device__ __forceinline__ void fft_stages(cpx<T> (&v)[Geo<LOG2NC>::PPL], cpx<T>
     if constexpr (LOGNS + RB < LOG2NC) fft_stages<T, LOG2NC, LOGNS + RB>(v, Z, l, tw);
 }
 
+// ------------------------------------------------------------------------------------------
+// Tile unpack: raw little-endian PCM bytes in LDS -> derived rows {L, R, mid, side} (main.c:198-207)
+// minus the row mean, pre-emphasised over the whole signal (PreEmphasise, call site main.c:208).
+// One lane produces 4 consecutive samples of every row and stores them as one 16-byte vector.
+// EXACT: double arithmetic with separately rounded multiply and subtract, bit-identical to the
+// reference's un-fused double code (needed whenever the sign of a sample is observable: ZCR).
+// ------------------------------------------------------------------------------------------
+
+template <typename T, bool EXACT, int CH>
+__device__ __forceinline__ void unpack_tile(T *rows, const unsigned *raw, int rowPitch, int V, int bps,
+                                            int mis, int lead, long long first, int ns,
+                                            const double *mean, double preK, int tid)
+{
+    using A = typename std::conditional<EXACT, double, float>::type; // arithmetic type
+    const A k = (A)preK;
+    const int bpi = CH * bps;
+    const int nq = (ns + 3) >> 2;
+    A mu[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) mu[v] = (A)mean[v];
+    for (int q = tid; q < nq; q += kBlock) {
+        const int s0 = 4 * q;
+        const bool hasPrev = (first + s0) > 0;           // false only for the signal's first sample
+        const int rel = s0 + lead - 1;                    // raw instant of the predecessor of s0
+        const int p0 = mis + (rel < 0 ? 0 : rel) * bpi;
+        A x[5][4]; // [instant: predecessor, s0 .. s0+3][row]
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int p = (rel < 0 && i > 0) ? p0 + (i - 1) * bpi : p0 + i * bpi;
+            const int c0 = lds_sample(raw, p, bps);
+            const int c1 = CH == 2 ? lds_sample(raw, p + bps, bps) : 0;
+            x[i][0] = (A)c0 - mu[0];
+            if (CH == 2) {
+                x[i][1] = (A)c1 - mu[1];
+                x[i][2] = (A)0.5 * ((A)c0 + (A)c1) - mu[2];
+                x[i][3] = ((A)c0 - (A)c1) - mu[3];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < (CH == 2 ? 4 : 1); ++v) {
+            if (v < V) {
+                T y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    A r;
+                    if constexpr (EXACT)
+                        r = sub_mul_exact(x[i + 1][v], x[i][v], k);
+                    else
+                        r = x[i + 1][v] - k * x[i][v];
+                    y[i] = (T)r;
+                }
+                if (!hasPrev) y[0] = (T)(x[1][v] * ((A)1 - k)); // s[1] *= 1 - k
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (s0 + i >= ns) y[i] = (T)0; // keeps the zero tail behind the tile intact
+                T *dst = rows + v * rowPitch + s0;
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+                } else {
+                    *reinterpret_cast<double2 *>(dst) = make_double2(y[0], y[1]);
+                    *reinterpret_cast<double2 *>(dst + 2) = make_double2(y[2], y[3]);
+                }
+            }
+        }
+    }
+}
+
+// Diagnostic build only (-DMFCC_STAMPS): per-phase cycle shares of the static-feature kernel,
+// summed over waves into FrontArgs::stamps.  Never compiled into the shipped library.
+#ifdef MFCC_STAMPS
+#define STAMP_DECL unsigned long long st_last = 0, st_acc[12] = {}; (void)st_last;
+#define STAMP_START                                             \
+    do {                                                        \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        st_last = __builtin_amdgcn_s_memtime();                 \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     \
+        __builtin_amdgcn_sched_barrier(0);                      \
+    } while (0)
+#define STAMP(i)                                                \
+    do {                                                        \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                     \
+        st_acc[i] += t_ - st_last;                              \
+        st_last = t_;                                           \
+        __builtin_amdgcn_sched_barrier(0);                      \
+    } while (0)
+#define STAMP_FLUSH                                                                        \
+    do {                                                                                   \
+        if ((threadIdx.x & 63) == 0 && a.stamps)                                           \
+            for (int i_ = 0; i_ < 12; ++i_) atomicAdd(a.stamps + i_, st_acc[i_]);          \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
 // Registers the compiler may use per lane, as waves per SIMD it has to leave room for.
 template <typename T, int LOG2NC>
 constexpr int front_waves_per_simd()
@@ -169,11 +270,11 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
     constexpr int NPAIR = PPL / 2 > 0 ? PPL / 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *ldsTab = reinterpret_cast<T *>(smem);        // [window | twiddles | split factors] if TLDS
+    T *ldsTab = reinterpret_cast<T *>(smem);        // table copies if TLDS (see below)
     T *rows = ldsTab + a.tabElems;                  // V x rowPitch pre-emphasised samples
     T *zbuf = rows + a.V * a.rowPitch;              // GROUPS work areas; raw PCM bytes alias it
     T *feat = zbuf + a.rawOrZElems;                 // framesPerTile x vSize static features
-    T *fbkSep = feat + a.framesPerTile * a.vSize;   // GROUPS x P log-mel values (if not in Z)
+    T *fbkSep = feat + a.featElems;                 // GROUPS x P log-mel values (cepstral mode)
     T *red = fbkSep + a.fbkElems;                   // 8 elements for cross-wave sums
     unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
 
@@ -181,18 +282,27 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
     const int l = tid & (G - 1), grp = tid / G;
     const int bpi = a.channels * a.bps;
 
-    const T *win = a.window, *tw = a.tw, *split = a.splitTw;
+    // tables: [window (winPad) | twiddles (2 nc) | split factors (nc) | loWt (nc) | chanRange (4 P)]
+    const T *win = a.window, *tw = a.tw, *split = a.splitTw, *lw = a.loWt;
+    const int4 *cr = reinterpret_cast<const int4 *>(a.chanRange);
     if constexpr (TLDS) {
-        T *w = ldsTab, *t = w + a.winPad, *sp = t + 2 * NC;
-        for (int i = tid; i < a.wlen; i += kBlock) w[i] = a.window[i];
+        T *w = ldsTab, *t = w + a.winPad, *sp = t + 2 * NC, *lo = sp + (NC > 1 ? NC : 2);
+        int *c = reinterpret_cast<int *>(lo + NC);
+        for (int i = tid; i < a.winPad; i += kBlock) w[i] = a.window[i];
         for (int i = tid; i < 2 * NC; i += kBlock) t[i] = a.tw[i];
         for (int i = tid; i < (NC > 1 ? NC : 2); i += kBlock) sp[i] = a.splitTw[i];
+        for (int i = tid; i < NC; i += kBlock) lo[i] = a.loWt[i];
+        for (int i = tid; i < 4 * a.P; i += kBlock) c[i] = a.chanRange[i];
         win = w;
         tw = t;
         split = sp;
+        lw = lo;
+        cr = reinterpret_cast<const int4 *>(c);
         __syncthreads();
     }
 
+    STAMP_DECL
+    STAMP_START;
     for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
         const int u = a.tileUtt[tile];
         const UttDesc ud = a.utts[u];
@@ -211,45 +321,27 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
         const int nvec = (mis + (ns + lead) * bpi + 15) >> 4;
         for (int i = tid; i < nvec; i += kBlock) reinterpret_cast<uint4 *>(raw)[i] = src[i];
         __syncthreads();
+        STAMP(0);
 
-        // A2: unpack, derive {L, R, mid, side}, subtract the row mean, pre-emphasise in double
-        // with separately rounded multiply and subtract (PreEmphasise, call site main.c:208).
-        for (int s = tid; s < ns; s += kBlock) {
-            const int rel = s + lead;
-            const bool hasPrev = (first + s) > 0;
-            double cur[4], prv[4];
-            {
-                const int p = mis + rel * bpi;
-                const int c0 = lds_sample(raw, p, a.bps);
-                const int c1 = a.channels == 2 ? lds_sample(raw, p + a.bps, a.bps) : 0;
-                cur[0] = (double)c0;
-                cur[1] = (double)c1;
-                cur[2] = 0.5 * ((double)c0 + (double)c1);
-                cur[3] = (double)c0 - (double)c1;
-            }
-            if (hasPrev) {
-                const int p = mis + (rel - 1) * bpi;
-                const int c0 = lds_sample(raw, p, a.bps);
-                const int c1 = a.channels == 2 ? lds_sample(raw, p + a.bps, a.bps) : 0;
-                prv[0] = (double)c0;
-                prv[1] = (double)c1;
-                prv[2] = 0.5 * ((double)c0 + (double)c1);
-                prv[3] = (double)c0 - (double)c1;
-            }
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                if (v < a.V) {
-                    const double x = cur[v] - ud.mean[v];
-                    double y;
-                    if (hasPrev)
-                        y = sub_mul_exact(x, prv[v] - ud.mean[v], a.preK);
-                    else
-                        y = x * (1.0 - a.preK);
-                    rows[v * a.rowPitch + s] = (T)y;
-                }
+        // A2: unpack / derive rows / remove mean / pre-emphasise (see unpack_tile)
+        {
+            const bool exact = sizeof(T) == 8 || a.zcFlag != 0;
+            if (a.channels == 2) {
+                if (exact)
+                    unpack_tile<T, true, 2>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
+                else
+                    unpack_tile<T, false, 2>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
+            } else {
+                if (exact)
+                    unpack_tile<T, true, 1>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
+                else
+                    unpack_tile<T, false, 1>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
             }
         }
+        for (int s = tid; s < a.rowTail; s += kBlock)
+            for (int v = 0; v < a.V; ++v) rows[v * a.rowPitch + ns + s] = (T)0;
         __syncthreads();
+        STAMP(1);
 
         const int nItems = nf * a.V;
         for (int base = 0; base < nItems; base += GROUPS) {
@@ -259,12 +351,16 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
             const T *x = rows + vv * a.rowPitch + fr * a.inc;
             T *Zt = zbuf + grp * GEO::ZPITCH;
             cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
-            T *Pw = Zt;                                   // power spectrum, nc values
-            T *fbk = a.fbkElems ? fbkSep + grp * a.P : Zt + NC; // log-mel values of this frame
+            T *Av = Zt, *Bv = Zt + NC;                    // per-bin loWt*p and p - loWt*p
+            T *Pw = Zt;                                   // plain power values, before Av / Bv
+            T *fbk = fbkSep + grp * a.P;                  // log-mel values (only if fbkElems)
             T *fo = feat + item * a.D;
 
             // ---- window, frame energy, zero crossings, first FFT stage input (Ham main.c:229,
             //      te mfcc.c:138-142, zero padding mfcc.c:144-147)
+            // Loads are unconditional and need no bounds test: rows are zero-filled for
+            // fftN - wlen + 2 elements behind the tile's last sample and the window table is
+            // zero from index wlen on (a Hamming window is > 0 inside, so w > 0 <=> index < wlen).
             cpx<T> v[PPL];
             T te = 0;
             int zc = 0;
@@ -274,114 +370,165 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
                 for (int r = 0; r < R0; ++r) {
                     const int n = l + G * b + r * (NC / R0);
                     const int s0 = 2 * n, s1 = s0 + 1;
-                    T x0 = 0, x1 = 0, x2 = 0;
-                    if (active && s0 < a.wlen) x0 = x[s0];
-                    if (active && s1 < a.wlen) x1 = x[s1];
-                    if (a.zcFlag) {
-                        if (active && s1 + 1 < a.wlen) x2 = x[s1 + 1];
-                        zc += ((x0 < 0 && x1 > 0) || (x0 > 0 && x1 < 0)) ? 1 : 0;
-                        zc += ((x1 < 0 && x2 > 0) || (x1 > 0 && x2 < 0)) ? 1 : 0;
-                    }
-                    const T w0 = s0 < a.wlen ? win[s0] : (T)0;
-                    const T w1 = s1 < a.wlen ? win[s1] : (T)0;
+                    T x0 = x[s0], x1 = x[s1];
+                    const T w0 = win[s0], w1 = win[s1];
                     x0 *= w0;
                     x1 *= w1;
                     te += x0 * x0 + x1 * x1;
                     v[b * R0 + r] = {x0, x1};
                 }
             }
+            STAMP(2);
             if (a.energyFlag) te = group_sum<T, G>(te, red, tid);
-            if (a.zcFlag) zc = group_sum<int, G>(zc, reinterpret_cast<int *>(red), tid);
+            if (a.zcFlag) { // sign changes between neighbours of the un-windowed frame (main.c:227)
+#pragma unroll
+                for (int i = 0; i < PPL; ++i) {
+                    const int s0 = 2 * (l + G * i);
+                    const T x0 = x[s0], x1 = x[s0 + 1], x2 = x[s0 + 2];
+                    const T w1 = win[s0 + 1], w2 = win[s0 + 2];
+                    const bool c01 = (x0 < 0 && x1 > 0) || (x0 > 0 && x1 < 0);
+                    const bool c12 = (x1 < 0 && x2 > 0) || (x1 > 0 && x2 < 0);
+                    zc += (c01 && w1 > 0) ? 1 : 0;
+                    zc += (c12 && w2 > 0) ? 1 : 0;
+                }
+                zc = group_sum<int, G>(zc, reinterpret_cast<int *>(red), tid);
+            }
 
             // ---- nc-point complex FFT of z[n] = x[2n] + i x[2n+1]   (Realft mfcc.c:262-270)
             fft_stages<T, LOG2NC, 0>(v, Z, l, tw);
+            STAMP(3);
 
             // ---- real-FFT split and power  (mfcc.c:274-290, ek of mfcc.c:153-155)
             // X[k] = E + w O, X[nc-k] = conj(E - w O), w = exp(-i pi k / nc); only |X|^2 is kept.
             T pa[NPAIR], pb[NPAIR];
 #pragma unroll
             for (int q = 0; q < NPAIR; ++q) {
-                const int k = l + G * q;
-                if (k == 0) {
-                    const cpx<T> z0 = Z[0], zh = Z[zpad(NC / 2)];
-                    pa[q] = (z0.x + z0.y) * (z0.x + z0.y);
-                    pb[q] = NC > 1 ? zh.x * zh.x + zh.y * zh.y : (T)0;
-                } else {
-                    const cpx<T> za = Z[zpad(k)], zb = Z[zpad(NC - k)];
-                    const T c = split[2 * k], s = split[2 * k + 1];
-                    const T ex = (T)0.5 * (za.x + zb.x), ey = (T)0.5 * (za.y - zb.y);
-                    const T ox = (T)0.5 * (za.y + zb.y), oy = (T)-0.5 * (za.x - zb.x);
-                    const T wx = c * ox + s * oy, wy = c * oy - s * ox;
-                    pa[q] = (ex + wx) * (ex + wx) + (ey + wy) * (ey + wy);
-                    pb[q] = (ex - wx) * (ex - wx) + (ey - wy) * (ey - wy);
-                }
+                const int k = l + G * q; // k == 0 (lane 0, q == 0) reads a don't-care word: fixed up below
+                const cpx<T> za = Z[zpad(k)], zb = Z[zpad(NC - k)];
+                const T c = split[2 * k], s = split[2 * k + 1];
+                const T ex = (T)0.5 * (za.x + zb.x), ey = (T)0.5 * (za.y - zb.y);
+                const T ox = (T)0.5 * (za.y + zb.y), oy = (T)-0.5 * (za.x - zb.x);
+                const T wx = c * ox + s * oy, wy = c * oy - s * ox;
+                pa[q] = (ex + wx) * (ex + wx) + (ey + wy) * (ey + wy);
+                pb[q] = (ex - wx) * (ex - wx) + (ey - wy) * (ey - wy);
             }
-            group_sync<G>();
+            {
+                // bin 0 packs Re + Im of Z[0] (mfcc.c:288-290); bin nc/2 is |Z[nc/2]|^2
+                const cpx<T> z0 = Z[0], zh = Z[zpad(NC / 2)];
+                const T p0 = (z0.x + z0.y) * (z0.x + z0.y);
+                const T ph = NC > 1 ? zh.x * zh.x + zh.y * zh.y : (T)0;
+                pa[0] = l == 0 ? p0 : pa[0];
+                pb[0] = l == 0 ? ph : pb[0];
+            }
+            // Brightness without sub-bands: power-weighted mean bin index straight from registers.
+            T regTotal = 0, regNum = 0;
+            if (a.brightFlag && a.S == 0) {
 #pragma unroll
-            for (int q = 0; q < NPAIR; ++q) {
-                const int k = l + G * q;
-                if (k == 0) {
-                    Pw[0] = pa[q];
-                    if (NC > 1) Pw[NC / 2] = pb[q];
-                } else {
-                    Pw[k] = pa[q];
-                    Pw[NC - k] = pb[q];
+                for (int q = 0; q < NPAIR; ++q) {
+                    const int k = l + G * q;
+                    const int k2 = k == 0 ? NC / 2 : NC - k;
+                    regTotal += pa[q] + pb[q];
+                    regNum += (T)(k + 1) * pa[q] + (T)(k2 + 1) * pb[q];
                 }
+                regTotal = group_sum<T, G>(regTotal, red, tid);
+                regNum = group_sum<T, G>(regNum, red, tid);
             }
-            group_sync<G>();
+            STAMP(4);
+            group_sync<G>(); // every lane has read its Z points: the work area can be reused
 
-            // ---- brightness and sub-band energies (call sites main.c:235-236)
-            if (a.brightFlag || a.S > 0) {
-                const int nseg = a.S > 0 ? a.S : 1;
-                const int width = NC / nseg;
-                const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
-                T total = 0, num = 0;
-                for (int g = 0; g < nseg; ++g) {
-                    const int lo = g * width, hi = (g == nseg - 1) ? NC : lo + width;
-                    T e = 0, ek = 0;
-                    for (int k = lo + l; k < hi; k += G) {
-                        const T pv = Pw[k];
-                        e += pv;
-                        ek += (T)(k + 1) * pv;
+            // ---- sub-band energies / brightness / debug magnitudes need the plain power values
+            //      of the whole frame: park them in the work area first (call sites main.c:235-236)
+            if (a.S > 0 || a.fftLength > 0) {
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) {
+                    const int k = l + G * q;
+                    const int k2 = k == 0 ? NC / 2 : NC - k;
+                    Pw[k] = pa[q];
+                    if (NC > 1) Pw[k2] = pb[q];
+                }
+                group_sync<G>();
+                if (a.S > 0) {
+                    const int nseg = a.S;
+                    const int width = NC / nseg;
+                    const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
+                    T total = 0, num = 0;
+                    for (int g = 0; g < nseg; ++g) {
+                        const int lo = g * width, hi = (g == nseg - 1) ? NC : lo + width;
+                        T e = 0, ek = 0;
+                        for (int k = lo + l; k < hi; k += G) {
+                            const T pv = Pw[k];
+                            e += pv;
+                            ek += (T)(k + 1) * pv;
+                        }
+                        e = group_sum<T, G>(e, red, tid);
+                        ek = group_sum<T, G>(ek, red, tid);
+                        if (active && l == 0) fo[subAt + g] = e;
+                        total += e;
+                        num += ek;
                     }
-                    e = group_sum<T, G>(e, red, tid);
-                    ek = group_sum<T, G>(ek, red, tid);
-                    if (active && l == 0 && a.S > 0) fo[subAt + g] = e;
-                    total += e;
-                    num += ek;
+                    if (active && l == 0) {
+                        if (a.brightFlag)
+                            fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / total / (T)NC;
+                        for (int g = 0; g < a.S; ++g) fo[subAt + g] = fo[subAt + g] / total;
+                    }
                 }
-                if (active && l == 0) {
-                    if (a.brightFlag)
-                        fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / total / (T)NC;
-                    for (int g = 0; g < a.S; ++g) fo[subAt + g] = fo[subAt + g] / total;
+                if (active && a.fftLength > 0) {                                   // main.c:247
+                    const int at = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag + a.S;
+                    for (int q = l; q < a.fftLength; q += G) fo[at + q] = tsqrt<T>(Pw[q]);
                 }
+                group_sync<G>();
             }
+            if (a.S == 0 && a.brightFlag && active && l == 0)
+                fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = regNum / regTotal / (T)NC;
             if (active && l == 0) {
                 if (a.energyFlag) fo[a.M + a.c0Flag] = tlog<T>(te);                // main.c:243
                 if (a.zcFlag)
                     fo[a.M + a.c0Flag + a.energyFlag] = (T)zc / (T)(a.wlen - 1);   // main.c:244
             }
-            if (active && a.fftLength > 0) {                                       // main.c:247
-                const int at = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag + a.S;
-                for (int q = l; q < a.fftLength; q += G) fo[at + q] = tsqrt<T>(Pw[q]);
-            }
 
-            // ---- mel filterbank, gather form of the two-tap scatter of mfcc.c:152-163, then
-            //      log(max(., 1))  (mfcc.c:171-176).  fbk sits behind the nc power values.
-            for (int ch = l; ch < a.P; ch += G) {
-                const int4 rg = reinterpret_cast<const int4 *>(a.chanRange)[ch];
-                T acc = 0;
-                for (int k = rg.x; k < rg.y; ++k) {
-                    const T pv = Pw[k];
-                    acc += pv - a.loWt[k] * pv;
+            // Per bin, exactly the two products of mfcc.c:160-162: t1 = loWt*ek and ek - t1.
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) {
+                const int k = l + G * q;
+                const int k2 = k == 0 ? NC / 2 : NC - k;
+                const T t1 = lw[k] * pa[q], t2 = lw[k2] * pb[q];
+                Av[k] = t1;
+                Bv[k] = pa[q] - t1;
+                if (NC > 1) {
+                    Av[k2] = t2;
+                    Bv[k2] = pb[q] - t2;
                 }
-                for (int k = rg.z; k < rg.w; ++k) acc += a.loWt[k] * Pw[k];
+            }
+            group_sync<G>();
+
+            STAMP(5);
+            // ---- mel filterbank, gather form of the two-tap scatter of mfcc.c:152-163: channel
+            //      b sums (ek - t1) over the bins whose lower channel is b-1, then t1 over the bins
+            //      whose lower channel is b, in bin order; then log(max(., 1))  (mfcc.c:171-176).
+            for (int ch = l; ch < a.P; ch += G) {
+                const int4 rg = cr[ch];
+                T acc = 0;
+                for (int k = rg.x; k < rg.y; k += 4) { // 4 loads in flight; reads past the range
+                    const T b0 = Bv[k], b1 = Bv[k + 1], b2 = Bv[k + 2], b3 = Bv[k + 3];
+                    acc += b0;                          // stay inside the work area and are dropped
+                    acc += k + 1 < rg.y ? b1 : (T)0;
+                    acc += k + 2 < rg.y ? b2 : (T)0;
+                    acc += k + 3 < rg.y ? b3 : (T)0;
+                }
+                for (int k = rg.z; k < rg.w; k += 4) {
+                    const T a0 = Av[k], a1 = Av[k + 1], a2 = Av[k + 2], a3 = Av[k + 3];
+                    acc += a0;
+                    acc += k + 1 < rg.w ? a1 : (T)0;
+                    acc += k + 2 < rg.w ? a2 : (T)0;
+                    acc += k + 3 < rg.w ? a3 : (T)0;
+                }
                 const T lv = tlog<T>(acc < (T)1 ? (T)1 : acc);
-                fbk[ch] = lv;
+                if (a.fbkElems) fbk[ch] = lv;
                 if (active && a.fbankFlag) fo[ch] = lv;
             }
             group_sync<G>();
 
+            STAMP(6);
             // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208)
             if (active && !a.fbankFlag) {
                 for (int j = l; j < a.M + a.c0Flag; j += G) {
@@ -396,8 +543,10 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
             }
             // the next round overwrites the work area: every lane of the frame is done with it
             group_sync<G>();
+            STAMP(7);
         }
         __syncthreads();
+        STAMP(8);
 
         // ---- tile rows -> HBM (static block of every row; delta slots are written later)
         const long long row0 = ud.outRow + f0;
@@ -405,7 +554,9 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
             const int r = i / a.vSize, c = i - r * a.vSize;
             a.out[(row0 + r) * a.step + c] = feat[i];
         }
+        STAMP(9);
     }
+    STAMP_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -699,7 +850,34 @@ int front_groups(int log2nc)
 int front_zpitch(int log2nc)
 {
     const int nc = 1 << log2nc;
-    return ((2 * (nc + nc / 16) + 2) + 3) & ~3;
+    return (2 * (nc + nc / 16) + 3) & ~3;
+}
+
+template <typename T, int L, bool TLDS>
+static int front_occ_t(size_t lds)
+{
+    int n = 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, TLDS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_front<T, L, TLDS>, kBlock, lds) != hipSuccess)
+        return 0;
+    return n;
+}
+
+// Workgroups of the static-feature kernel that the runtime says fit one CU (0 = unknown).
+int front_occupancy(int precision, int log2nc, bool tabLds, size_t ldsBytes)
+{
+    switch (log2nc) {
+#define MFCC_CASE(L)                                                                            \
+    case L:                                                                                     \
+        return precision == 1                                                                   \
+                   ? (tabLds ? front_occ_t<double, L, true>(ldsBytes) : front_occ_t<double, L, false>(ldsBytes)) \
+                   : (tabLds ? front_occ_t<float, L, true>(ldsBytes) : front_occ_t<float, L, false>(ldsBytes));
+        MFCC_CASE(1) MFCC_CASE(2) MFCC_CASE(3) MFCC_CASE(4) MFCC_CASE(5) MFCC_CASE(6) MFCC_CASE(7)
+        MFCC_CASE(8) MFCC_CASE(9) MFCC_CASE(10) MFCC_CASE(11) MFCC_CASE(12) MFCC_CASE(13)
+#undef MFCC_CASE
+    default: return 0;
+    }
 }
 
 int front_waves_limit(int precision, int log2nc)
