@@ -35,7 +35,6 @@ struct MFCCContext {
     int device = 0;
     int M = 0, c0 = 0, D = 0, vSize = 0, step = 0;
     void *dWindow = nullptr, *dTw = nullptr, *dSplitTw = nullptr, *dLoWt = nullptr, *dDct = nullptr;
-    int32_t *dChanRange = nullptr;
 };
 
 struct MFCCPlan {
@@ -47,10 +46,14 @@ struct MFCCPlan {
     int numTiles = 0, numChunks = 0;
     int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0;
     int tabElems = 0, winPad = 0, featElems = 0, fbkElems = 0, rowTail = 0;
-    int blocksPerCu = 1, numCus = 256;
+    int blocksPerCu = 1, numCus = 256, pplog = 4;
     size_t ldsBytes = 0;
     UttDesc *dUtts = nullptr;
-    int32_t *dTileUtt = nullptr, *dChunkUtt = nullptr;
+    int32_t *dTileUtt = nullptr, *dChunkUtt = nullptr, *dLaneSeg = nullptr;
+    void *dStageTw = nullptr;
+    std::vector<double> stageTw;
+    int maxSeg = 1, zPitch = 0;
+    std::vector<int32_t> laneSeg;
     double *dPartial = nullptr, *dStats = nullptr;
     unsigned long long *dSums2 = nullptr;
     int64_t sampleBegin = 0, sampleCount = 0, ownedRowBegin = 0, ownedRows = 0;
@@ -112,9 +115,6 @@ extern "C" int MFCCContextCreate(const MFCCConfig *cfgIn, int device, MFCCContex
     if ((rc = upload_tab(p, c->tab.splitTw, &c->dSplitTw))) return rc;
     if ((rc = upload_tab(p, c->tab.loWt, &c->dLoWt))) return rc;
     if ((rc = upload_tab(p, c->tab.dct, &c->dDct))) return rc;
-    HIP_TRY(hipMalloc((void **)&c->dChanRange, c->tab.chanRange.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(c->dChanRange, c->tab.chanRange.data(),
-                      c->tab.chanRange.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     *out = c.release();
     return MFCC_OK;
 }
@@ -128,7 +128,6 @@ extern "C" void MFCCContextDestroy(MFCCContext *c)
     (void)hipFree(c->dSplitTw);
     (void)hipFree(c->dLoWt);
     (void)hipFree(c->dDct);
-    (void)hipFree(c->dChanRange);
     delete c;
 }
 
@@ -164,18 +163,77 @@ static int choose_tile(MFCCPlan *p)
     const MFCCContext *c = p->ctx;
     const int V = c->cfg.vecNum, log2nc = c->tab.log2nc, prec = c->cfg.precision;
     const int nc = c->tab.nc, P = c->cfg.bankNum;
-    const int groups = front_groups(log2nc), zPitch = front_zpitch(log2nc);
+    // complex points per lane = 2^pplog: 8 points (radix-8 stages) measured fastest on MI355X
+    // where that variant exists, 16 otherwise
+    int pplog = front_variant_exists(log2nc, 3) ? 3 : 4;
+    if (const char *e = getenv("MFCC_PPLOG")) // tuning aid
+        if (front_variant_exists(log2nc, atoi(e))) pplog = atoi(e);
+    p->pplog = pplog;
+    const int groups = front_groups(log2nc, pplog), lanes = front_lanes(log2nc, pplog);
+    // work area of one frame: nc complex points with one pad point per 16, or the nc (t1, ek-t1)
+    // pairs followed by the 2 (P+1) segment sums, whichever is larger
+    const int zPitch = (std::max(2 * (nc + nc / 16), 2 * nc + 2 * (c->cfg.bankNum + 1)) + 3) & ~3;
+    p->zPitch = zPitch;
+    {
+        // Per-stage twiddle blocks, laid out as the kernel's fft_stages reads them: for a stage
+        // with sub-transform size NS and radix R (R = 2^min(rbmax, remaining bits)), entries
+        // [r-1][m] = exp(-2 pi i r m / (NS R)), m < NS; the first stage (NS = 1) has none.
+        const int rbmax = std::min(pplog, 4);
+        p->stageTw.clear();
+        for (int logns = 0; logns < log2nc;) {
+            const int rb = std::min(rbmax, log2nc - logns), R = 1 << rb, NS = 1 << logns;
+            if (logns > 0)
+                for (int r = 1; r < R; ++r)
+                    for (int m = 0; m < NS; ++m) {
+                        const double ang = 2.0 * M_PI * (double)r * (double)m / ((double)NS * R);
+                        p->stageTw.push_back(cos(ang));
+                        p->stageTw.push_back(-sin(ang));
+                    }
+            logns += rb;
+        }
+        p->stageTw.resize(2 * (size_t)nc + 8, 0.0); // the kernel stages 2 nc elements into LDS
+    }
+    {
+        // Mel segments: segment s (0..P) = the bins whose lower channel is s (contiguous, because
+        // loChan never decreases over the pass band).  Longest first, each to the least loaded lane.
+        const int P1 = c->cfg.bankNum + 1;
+        std::vector<int> sb(P1, 0), se(P1, 0);
+        for (int k = 0; k < nc; ++k) {
+            const int ch = c->tab.loChan[k];
+            if (ch < 0 || ch >= P1) continue;
+            if (se[ch] == 0) sb[ch] = k;
+            se[ch] = k + 1;
+        }
+        p->maxSeg = (P1 + lanes - 1) / lanes;
+        std::vector<int> order(P1), load(lanes, 0), count(lanes, 0);
+        for (int i = 0; i < P1; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int x, int y) { return se[x] - sb[x] > se[y] - sb[y]; });
+        p->laneSeg.assign((size_t)lanes * p->maxSeg * 4, 0);
+        for (size_t i = 0; i < (size_t)lanes * p->maxSeg; ++i) p->laneSeg[4 * i + 2] = -1;
+        for (int s : order) {
+            int best = -1;
+            for (int ln = 0; ln < lanes; ++ln)
+                if (count[ln] < p->maxSeg && (best < 0 || load[ln] < load[best])) best = ln;
+            int32_t *e = &p->laneSeg[((size_t)best * p->maxSeg + count[best]) * 4];
+            e[0] = sb[s];
+            e[1] = se[s];
+            e[2] = s;
+            load[best] += std::max(se[s] - sb[s], 1);
+            ++count[best];
+        }
+    }
     const size_t el = prec == MFCC_PREC_F64 ? 8 : 4;
     const int bpi = p->channels * p->bps;
     const int base = (groups + V - 1) / V;
     const size_t kLds = 160 * 1024;
     const int rowTail = c->tab.fftN - c->cfg.wlen + 2; // zero-filled, so frame loads need no bounds test
     p->rowTail = rowTail;
-    const int wavesCap = front_waves_limit(prec, log2nc); // workgroups per CU the registers allow
+    const int wavesCap = front_waves_limit(prec, log2nc, pplog); // workgroups per CU the registers allow
     p->winPad = (c->tab.fftN + 2 + 3) & ~3; // window values, then zeros up to fftN + 2
     p->fbkElems = c->cfg.fbankFlag ? 0 : ((groups * P + 3) & ~3);
     const size_t tabElems = (((size_t)p->winPad + 2 * (size_t)nc + (size_t)std::max(nc, 2) + (size_t)nc +
-                              4 * (size_t)P) + 3) & ~(size_t)3;
+                              4 * (size_t)lanes * p->maxSeg) + 3) & ~(size_t)3;
     auto geometry = [&](int ft, bool tabLds, int &rowPitch, int &rawOrZ) {
         const long ninst = (long)(ft - 1) * c->cfg.inc + c->cfg.wlen + 1;
         rowPitch = (int)((ninst + rowTail + 3) & ~3L);
@@ -227,10 +285,10 @@ static int choose_tile(MFCCPlan *p)
     p->blocksPerCu = bestBlocks;
     p->ldsBytes = geometry(bestFt, bestTab, p->rowPitch, p->rawOrZElems);
     p->featElems = (int)(((size_t)bestFt * c->vSize + 3) & ~(size_t)3);
-    const int occ = front_occupancy(prec, log2nc, bestTab, p->ldsBytes);
+    const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->ldsBytes);
     if (getenv("MFCC_DEBUG"))
-        fprintf(stderr, "mfcc plan: framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
-                bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
+        fprintf(stderr, "mfcc plan: points/lane %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
+                1 << pplog, bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
     if (occ > 0 && occ < p->blocksPerCu) p->blocksPerCu = occ;
     if (const char *e = getenv("MFCC_BLOCKS_PER_CU")) // tuning aid: resident workgroups per CU
         if (atoi(e) > 0) p->blocksPerCu = atoi(e);
@@ -277,6 +335,12 @@ static int finish_plan(MFCCPlan *p)
     HIP_TRY(hipMalloc((void **)&p->dTileUtt, std::max<size_t>(tileUtt.size(), 1) * sizeof(int32_t)));
     if (!tileUtt.empty())
         HIP_TRY(hipMemcpy(p->dTileUtt, tileUtt.data(), tileUtt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    {
+        const int rc2 = upload_tab(c->cfg.precision, p->stageTw, &p->dStageTw);
+        if (rc2) return rc2;
+    }
+    HIP_TRY(hipMalloc((void **)&p->dLaneSeg, std::max<size_t>(p->laneSeg.size(), 4) * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p->dLaneSeg, p->laneSeg.data(), p->laneSeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     const bool needStats = c->cfg.znormFlag != 0;
     if (needStats) {
         HIP_TRY(hipMalloc((void **)&p->dChunkUtt, std::max<size_t>(chunkUtt.size(), 1) * sizeof(int32_t)));
@@ -392,6 +456,8 @@ extern "C" void MFCCPlanDestroy(MFCCPlan *p)
     (void)hipFree(p->dUtts);
     (void)hipFree(p->dTileUtt);
     (void)hipFree(p->dChunkUtt);
+    (void)hipFree(p->dLaneSeg);
+    (void)hipFree(p->dStageTw);
     (void)hipFree(p->dPartial);
     (void)hipFree(p->dStats);
     (void)hipFree(p->dSums2);
@@ -471,10 +537,13 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.preK = c->cfg.preemphasise;
     a.mfnorm = (T)c->tab.mfnorm;
     a.window = static_cast<const T *>(c->dWindow);
-    a.tw = static_cast<const T *>(c->dTw);
+    a.tw = static_cast<const T *>(p->dStageTw);
     a.splitTw = static_cast<const T *>(c->dSplitTw);
     a.loWt = static_cast<const T *>(c->dLoWt);
-    a.chanRange = c->dChanRange;
+    a.laneSeg = p->dLaneSeg;
+    a.maxSeg = p->maxSeg;
+    a.pairAligned = (c->cfg.inc % 2 == 0) ? 1 : 0;
+    a.zPitch = p->zPitch;
     a.dct = static_cast<const T *>(c->dDct);
     a.rowPitch = p->rowPitch;
     a.rowTail = p->rowTail;
@@ -484,6 +553,7 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.featElems = p->featElems;
     a.fbkElems = p->fbkElems;
     a.stamps = nullptr;
+    a.skip = 0;
 #ifdef MFCC_STAMPS
     {
         static unsigned long long *dStamps = nullptr;
@@ -502,11 +572,12 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
             HIP_TRY(hipMemset(dStamps, 0, 12 * sizeof(unsigned long long)));
         }
         a.stamps = dStamps;
+        if (const char *e = getenv("MFCC_SKIP")) a.skip = atoi(e);
     }
 #endif
     // persistent workgroups: as many as stay resident, each walks tiles with a grid stride
     const int blocks = (int)std::min<int64_t>(p->numTiles, (int64_t)p->numCus * p->blocksPerCu);
-    const int rc = launch_front(c->cfg.precision, c->tab.log2nc, &a, blocks, p->ldsBytes, stream);
+    const int rc = launch_front(c->cfg.precision, c->tab.log2nc, p->pplog, &a, blocks, p->ldsBytes, stream);
     if (rc) return set_error("static-feature kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;
 }

@@ -6,8 +6,11 @@
 
 namespace mfcc {
 
+// Aligned to its full size so that LDS accesses are single ds_read_b64 / ds_write_b64 (b128 for
+// double) instructions; as two 4-byte halves they would hit the 32-bank path at stride 2 and
+// take a 2-way bank conflict on every access.
 template <typename T>
-struct cpx {
+struct alignas(2 * sizeof(T)) cpx {
     T x, y;
 };
 

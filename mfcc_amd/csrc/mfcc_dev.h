@@ -43,7 +43,10 @@ struct FrontArgs {
     const T *tw;           // nc complex (cos, -sin)(2 pi m / nc), interleaved
     const T *splitTw;      // nc/2 complex (cos, sin)(pi a / nc), interleaved
     const T *loWt;         // nc
-    const int32_t *chanRange; // P x 4: [hiBegin, hiEnd) bins taken with (1 - loWt), [loBegin, loEnd) with loWt
+    const int32_t *laneSeg;   // lanes-per-frame x maxSeg x 4: {first bin, end bin, segment index or -1, 0}
+    int maxSeg;               // mel segments (bins sharing one lower channel) a lane sums at most
+    int pairAligned;          // 1: every frame starts on an even sample of its row (inc is even)
+    int zPitch;               // elements per frame work area
     const T *dct;          // P x M, k-major: cos(pi (j+1) (k + 0.5) / P)
     int rowPitch;          // elements per derived row in LDS
     int rowTail;           // elements zero-filled behind the last sample of a tile (>= fftN - wlen + 1)
@@ -53,6 +56,7 @@ struct FrontArgs {
     int featElems;         // elements of the static-feature staging area (framesPerTile x vSize, padded)
     int fbkElems;          // elements of the log-mel area, GROUPS x P (0 in filterbank mode)
     unsigned long long *stamps; // diagnostic builds only: 12 per-phase cycle sums (else NULL)
+    int skip;                   // diagnostic builds only: bit mask of phases to leave out
 };
 
 template <typename T>
@@ -77,12 +81,13 @@ struct StatArgs {
     double *stats;   // numUtts x 2*step : mean, 1/std  (batch plans)  or  shard sums (2*step+1)
 };
 
-int launch_front(int precision, int log2nc, const void *args, int numBlocks, size_t ldsBytes,
-                 void *stream);
-int front_groups(int log2nc);   // frame groups per workgroup
-int front_zpitch(int log2nc);   // elements per work area
-int front_waves_limit(int precision, int log2nc); // waves per SIMD the kernel is compiled for
-int front_occupancy(int precision, int log2nc, bool tabLds, size_t ldsBytes);
+int launch_front(int precision, int log2nc, int pplog, const void *args, int numBlocks,
+                 size_t ldsBytes, void *stream);
+bool front_variant_exists(int log2nc, int pplog); // pplog: log2 of complex points per lane (4, 3, 2)
+int front_groups(int log2nc, int pplog);          // frames in flight per workgroup
+int front_lanes(int log2nc, int pplog);           // lanes that share one frame
+int front_waves_limit(int precision, int log2nc, int pplog); // waves per SIMD the kernel is compiled for
+int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, size_t ldsBytes);
 int launch_regress(int precision, const void *args, int numTiles, void *stream);
 int launch_colstats(int precision, const void *args, int numChunks, void *stream);
 int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream);

@@ -22,7 +22,7 @@ struct Tables {
     int fftN = 0, nc = 0, log2nc = 0, klo = 0, khi = 0;
     double fres = 0, mlo = 0, mhi = 0, mfnorm = 0;
     std::vector<double> cf, loWt, window, dct, tw, splitTw;
-    std::vector<int32_t> loChan, chanRange;
+    std::vector<int32_t> loChan;
 };
 
 int build_tables(const MFCCConfig &cfg, Tables &t);

@@ -16,18 +16,22 @@
 
 namespace mfcc {
 
-template <int LOG2NC>
+// PPLOG: log2 of the complex points a lane keeps in registers (4 -> radix-16 stages, 3 -> radix-8,
+// 2 -> radix-4).  Fewer points per lane means more lanes per frame, fewer frames in flight per
+// wave, smaller work areas and fewer registers, i.e. more resident waves, at the price of more
+// exchange stages through LDS.
+template <int LOG2NC, int PPLOG>
 struct Geo {
     static constexpr int NC = 1 << LOG2NC;                        // complex FFT length = fftN / 2
-    static constexpr int G = NC >= 16 ? (NC / 16 > kBlock ? kBlock : NC / 16) : 1; // lanes per frame
+    static constexpr int PPL0 = 1 << (PPLOG < LOG2NC ? PPLOG : LOG2NC);
+    static constexpr int G = NC / PPL0 > kBlock ? kBlock : NC / PPL0; // lanes per frame
     static constexpr int PPL = NC / G;                            // complex points per lane
+    static constexpr int RBMAX = PPLOG < 4 ? PPLOG : 4;           // log2 of the largest stage radix
     static constexpr int GROUPS = kBlock / G;                     // frames in flight per workgroup
-    // work area: nc complex points, one pad point after every 16 (so that the 16x16 exchange
-    // between two radix-16 stages is free of LDS bank conflicts), rounded to a multiple of 4
-    static constexpr int ZPITCH = (2 * (NC + NC / 16) + 3) & ~3;
 };
 
-// index of complex point i inside a work area
+// Index of complex point i inside a work area: one pad point after every 16, so that the
+// transposing exchange between two FFT stages stays (nearly) free of LDS bank conflicts.
 __device__ __forceinline__ int zpad(int i) { return i + (i >> 4); }
 
 // ------------------------------------------------------------------------------------------
@@ -109,13 +113,19 @@ __device__ __forceinline__ double tsqrt<double>(double x) { return sqrt(x); }
 // w^{r (j mod NS) nc/(NS R)}, takes the R-point DFT and writes (j/NS) NS R + (j mod NS) + r NS.
 // ------------------------------------------------------------------------------------------
 
-template <typename T, int LOG2NC, int LOGNS>
-__device__ __forceinline__ void fft_stages(cpx<T> (&v)[Geo<LOG2NC>::PPL], cpx<T> *Z, int l,
-                                           const T *tw)
+template <typename T, int LOG2NC, int PPLOG>
+using LanePoints = cpx<T>[Geo<LOG2NC, PPLOG>::PPL]; // the complex points one lane holds
+
+// Twiddles are stored per stage, [r-1][j mod NS] = exp(-2 pi i r (j mod NS) / (NS R)), so that the
+// lanes of a wave read consecutive (or identical) 8-byte words: no LDS bank conflicts.  TWOFF is
+// the complex offset of this stage's block in that table (the blocks follow each other).
+template <typename T, int LOG2NC, int PPLOG, int LOGNS, int TWOFF>
+__device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<T> *Z, int l,
+                                           const cpx<T> *tw)
 {
-    using GEO = Geo<LOG2NC>;
+    using GEO = Geo<LOG2NC, PPLOG>;
     constexpr int NC = GEO::NC, G = GEO::G, PPL = GEO::PPL;
-    constexpr int RB = (LOG2NC - LOGNS) < 4 ? (LOG2NC - LOGNS) : 4;
+    constexpr int RB = (LOG2NC - LOGNS) < GEO::RBMAX ? (LOG2NC - LOGNS) : GEO::RBMAX;
     constexpr int R = 1 << RB, NS = 1 << LOGNS, NB = PPL / R, STRIDE = NC / R;
     if constexpr (LOGNS > 0) {
 #pragma unroll
@@ -126,14 +136,9 @@ __device__ __forceinline__ void fft_stages(cpx<T> (&v)[Geo<LOG2NC>::PPL], cpx<T>
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int j = l + G * b;
-            const int base = (j & (NS - 1)) * (NC / (NS * R));
+            const int m = (l + G * b) & (NS - 1);
 #pragma unroll
-            for (int r = 1; r < R; ++r) {
-                const int idx = r * base;
-                const cpx<T> w = {tw[2 * idx], tw[2 * idx + 1]};
-                v[b * R + r] = cmul(v[b * R + r], w);
-            }
+            for (int r = 1; r < R; ++r) v[b * R + r] = cmul(v[b * R + r], tw[TWOFF + (r - 1) * NS + m]);
         }
         group_sync<G>(); // every read of Z is done before any lane overwrites it
     }
@@ -147,7 +152,8 @@ __device__ __forceinline__ void fft_stages(cpx<T> (&v)[Geo<LOG2NC>::PPL], cpx<T>
         for (int r = 0; r < R; ++r) Z[zpad(o + r * NS)] = v[b * R + r];
     }
     group_sync<G>();
-    if constexpr (LOGNS + RB < LOG2NC) fft_stages<T, LOG2NC, LOGNS + RB>(v, Z, l, tw);
+    if constexpr (LOGNS + RB < LOG2NC)
+        fft_stages<T, LOG2NC, PPLOG, LOGNS + RB, TWOFF + (LOGNS > 0 ? (R - 1) * NS : 0)>(v, Z, l, tw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -242,31 +248,39 @@ __device__ __forceinline__ void unpack_tile(T *rows, const unsigned *raw, int ro
         if ((threadIdx.x & 63) == 0 && a.stamps)                                           \
             for (int i_ = 0; i_ < 12; ++i_) atomicAdd(a.stamps + i_, st_acc[i_]);          \
     } while (0)
+#define SKIP(b) ((a.skip >> (b)) & 1) // ablation: results are wrong, only counters / time matter
 #else
 #define STAMP_DECL
 #define STAMP_START
 #define STAMP(i)
 #define STAMP_FLUSH
+#define SKIP(b) false
 #endif
 
 // Registers the compiler may use per lane, as waves per SIMD it has to leave room for.
-template <typename T, int LOG2NC>
+constexpr int front_waves_rule(bool f64, int log2nc, int pplog)
+{
+    if (pplog == 4) return f64 ? (log2nc <= 7 ? 2 : 1) : (log2nc <= 9 ? 3 : (log2nc <= 11 ? 2 : 1));
+    if (pplog == 3) return f64 ? 2 : 4;
+    return f64 ? 3 : 5;
+}
+template <typename T, int LOG2NC, int PPLOG>
 constexpr int front_waves_per_simd()
 {
-    return sizeof(T) == 4 ? (LOG2NC <= 9 ? 3 : (LOG2NC <= 11 ? 2 : 1)) : (LOG2NC <= 7 ? 2 : 1);
+    return front_waves_rule(sizeof(T) == 8, LOG2NC, PPLOG);
 }
 
 // ------------------------------------------------------------------------------------------
 // Fused static-feature kernel.  TLDS: window / twiddle / split tables are staged in LDS.
 // ------------------------------------------------------------------------------------------
 
-template <typename T, int LOG2NC, bool TLDS>
-__global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k_front(
+template <typename T, int LOG2NC, int PPLOG, bool TLDS>
+__global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>())) void k_front(
     const FrontArgs<T> a)
 {
-    using GEO = Geo<LOG2NC>;
+    using GEO = Geo<LOG2NC, PPLOG>;
     constexpr int NC = GEO::NC, G = GEO::G, PPL = GEO::PPL, GROUPS = GEO::GROUPS;
-    constexpr int R0B = LOG2NC < 4 ? LOG2NC : 4, R0 = 1 << R0B; // radix of the first stage
+    constexpr int R0B = LOG2NC < GEO::RBMAX ? LOG2NC : GEO::RBMAX, R0 = 1 << R0B; // first-stage radix
     constexpr int NPAIR = PPL / 2 > 0 ? PPL / 2 : 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -282,9 +296,9 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
     const int l = tid & (G - 1), grp = tid / G;
     const int bpi = a.channels * a.bps;
 
-    // tables: [window (winPad) | twiddles (2 nc) | split factors (nc) | loWt (nc) | chanRange (4 P)]
+    // tables: [window (winPad) | twiddles (2 nc) | split factors (nc) | loWt (nc) | laneSeg (4 G maxSeg)]
     const T *win = a.window, *tw = a.tw, *split = a.splitTw, *lw = a.loWt;
-    const int4 *cr = reinterpret_cast<const int4 *>(a.chanRange);
+    const int4 *lseg = reinterpret_cast<const int4 *>(a.laneSeg);
     if constexpr (TLDS) {
         T *w = ldsTab, *t = w + a.winPad, *sp = t + 2 * NC, *lo = sp + (NC > 1 ? NC : 2);
         int *c = reinterpret_cast<int *>(lo + NC);
@@ -292,12 +306,12 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
         for (int i = tid; i < 2 * NC; i += kBlock) t[i] = a.tw[i];
         for (int i = tid; i < (NC > 1 ? NC : 2); i += kBlock) sp[i] = a.splitTw[i];
         for (int i = tid; i < NC; i += kBlock) lo[i] = a.loWt[i];
-        for (int i = tid; i < 4 * a.P; i += kBlock) c[i] = a.chanRange[i];
+        for (int i = tid; i < 4 * G * a.maxSeg; i += kBlock) c[i] = a.laneSeg[i];
         win = w;
         tw = t;
         split = sp;
         lw = lo;
-        cr = reinterpret_cast<const int4 *>(c);
+        lseg = reinterpret_cast<const int4 *>(c);
         __syncthreads();
     }
 
@@ -319,12 +333,13 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
         const int mis = (int)(gaddr & 15ull);
         const uint4 *src = reinterpret_cast<const uint4 *>(gaddr - mis);
         const int nvec = (mis + (ns + lead) * bpi + 15) >> 4;
-        for (int i = tid; i < nvec; i += kBlock) reinterpret_cast<uint4 *>(raw)[i] = src[i];
+        if (!SKIP(7))
+            for (int i = tid; i < nvec; i += kBlock) reinterpret_cast<uint4 *>(raw)[i] = src[i];
         __syncthreads();
         STAMP(0);
 
         // A2: unpack / derive rows / remove mean / pre-emphasise (see unpack_tile)
-        {
+        if (!SKIP(0)) {
             const bool exact = sizeof(T) == 8 || a.zcFlag != 0;
             if (a.channels == 2) {
                 if (exact)
@@ -349,10 +364,11 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
             const bool active = item < nItems;
             const int fr = active ? item / a.V : 0, vv = active ? item - fr * a.V : 0;
             const T *x = rows + vv * a.rowPitch + fr * a.inc;
-            T *Zt = zbuf + grp * GEO::ZPITCH;
+            T *Zt = zbuf + grp * a.zPitch;
             cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
-            T *Av = Zt, *Bv = Zt + NC;                    // per-bin loWt*p and p - loWt*p
-            T *Pw = Zt;                                   // plain power values, before Av / Bv
+            cpx<T> *AB = Z;                               // per bin (loWt*p, p - loWt*p)
+            T *Tt = Zt + 2 * NC, *Ut = Tt + a.P + 1;      // per-segment sums of the two
+            T *Pw = Zt;                                   // plain power values, before AB
             T *fbk = fbkSep + grp * a.P;                  // log-mel values (only if fbkElems)
             T *fo = feat + item * a.D;
 
@@ -364,14 +380,27 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
             cpx<T> v[PPL];
             T te = 0;
             int zc = 0;
+            if (SKIP(1)) {
+#pragma unroll
+                for (int i = 0; i < PPL; ++i) v[i] = {(T)(l + i), (T)(grp - i)};
+            } else
 #pragma unroll
             for (int b = 0; b < PPL / R0; ++b) {
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
                     const int n = l + G * b + r * (NC / R0);
-                    const int s0 = 2 * n, s1 = s0 + 1;
-                    T x0 = x[s0], x1 = x[s1];
-                    const T w0 = win[s0], w1 = win[s1];
+                    const int s0 = 2 * n;
+                    T x0, x1;
+                    if (a.pairAligned) { // frame starts on an even sample: one 2-element LDS read
+                        const cpx<T> xv = *reinterpret_cast<const cpx<T> *>(x + s0);
+                        x0 = xv.x;
+                        x1 = xv.y;
+                    } else {
+                        x0 = x[s0];
+                        x1 = x[s0 + 1];
+                    }
+                    const cpx<T> wv = *reinterpret_cast<const cpx<T> *>(win + s0);
+                    const T w0 = wv.x, w1 = wv.y;
                     x0 *= w0;
                     x1 *= w1;
                     te += x0 * x0 + x1 * x1;
@@ -395,17 +424,25 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
             }
 
             // ---- nc-point complex FFT of z[n] = x[2n] + i x[2n+1]   (Realft mfcc.c:262-270)
-            fft_stages<T, LOG2NC, 0>(v, Z, l, tw);
+            if (!SKIP(2)) fft_stages<T, LOG2NC, PPLOG, 0, 0>(v, Z, l, reinterpret_cast<const cpx<T> *>(tw));
             STAMP(3);
 
             // ---- real-FFT split and power  (mfcc.c:274-290, ek of mfcc.c:153-155)
             // X[k] = E + w O, X[nc-k] = conj(E - w O), w = exp(-i pi k / nc); only |X|^2 is kept.
             T pa[NPAIR], pb[NPAIR];
+            if (SKIP(3)) {
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) {
+                    pa[q] = v[q].x * v[q].x + (T)1;
+                    pb[q] = v[q].y * v[q].y + (T)1;
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < NPAIR; ++q) {
                 const int k = l + G * q; // k == 0 (lane 0, q == 0) reads a don't-care word: fixed up below
                 const cpx<T> za = Z[zpad(k)], zb = Z[zpad(NC - k)];
-                const T c = split[2 * k], s = split[2 * k + 1];
+                const cpx<T> sw = reinterpret_cast<const cpx<T> *>(split)[k];
+                const T c = sw.x, s = sw.y;
                 const T ex = (T)0.5 * (za.x + zb.x), ey = (T)0.5 * (za.y - zb.y);
                 const T ox = (T)0.5 * (za.y + zb.y), oy = (T)-0.5 * (za.x - zb.x);
                 const T wx = c * ox + s * oy, wy = c * oy - s * ox;
@@ -487,42 +524,43 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
             }
 
             // Per bin, exactly the two products of mfcc.c:160-162: t1 = loWt*ek and ek - t1.
+            if (SKIP(4)) {
+                asm volatile("" ::"v"(pa[0]), "v"(pb[NPAIR - 1]));
+            } else
 #pragma unroll
             for (int q = 0; q < NPAIR; ++q) {
                 const int k = l + G * q;
                 const int k2 = k == 0 ? NC / 2 : NC - k;
                 const T t1 = lw[k] * pa[q], t2 = lw[k2] * pb[q];
-                Av[k] = t1;
-                Bv[k] = pa[q] - t1;
-                if (NC > 1) {
-                    Av[k2] = t2;
-                    Bv[k2] = pb[q] - t2;
-                }
+                AB[k] = {t1, pa[q] - t1};
+                if (NC > 1) AB[k2] = {t2, pb[q] - t2};
             }
             group_sync<G>();
 
             STAMP(5);
-            // ---- mel filterbank, gather form of the two-tap scatter of mfcc.c:152-163: channel
-            //      b sums (ek - t1) over the bins whose lower channel is b-1, then t1 over the bins
-            //      whose lower channel is b, in bin order; then log(max(., 1))  (mfcc.c:171-176).
-            for (int ch = l; ch < a.P; ch += G) {
-                const int4 rg = cr[ch];
-                T acc = 0;
-                for (int k = rg.x; k < rg.y; k += 4) { // 4 loads in flight; reads past the range
-                    const T b0 = Bv[k], b1 = Bv[k + 1], b2 = Bv[k + 2], b3 = Bv[k + 3];
-                    acc += b0;                          // stay inside the work area and are dropped
-                    acc += k + 1 < rg.y ? b1 : (T)0;
-                    acc += k + 2 < rg.y ? b2 : (T)0;
-                    acc += k + 3 < rg.y ? b3 : (T)0;
+            // ---- mel filterbank (mfcc.c:152-163).  The bins whose lower channel is c form one
+            //      contiguous segment; its sums T[c] = sum t1 and U[c] = sum (ek - t1) are taken in
+            //      bin order, by the lane the host's balancing gave the segment to, and channel b is
+            //      U[b-1] + T[b]; then log(max(., 1))  (mfcc.c:171-176).
+            for (int sidx = 0; sidx < (SKIP(5) ? 0 : a.maxSeg); ++sidx) {
+                const int4 sg = lseg[l * a.maxSeg + sidx];
+                cpx<T> acc = {0, 0};
+                for (int k = sg.x; k < sg.y; k += 4) { // 4 loads in flight; reads past the segment
+                    const cpx<T> v0 = AB[k], v1 = AB[k + 1], v2 = AB[k + 2], v3 = AB[k + 3];
+                    acc = cadd(acc, v0);                // stay inside the work area and are dropped
+                    if (k + 1 < sg.y) acc = cadd(acc, v1);
+                    if (k + 2 < sg.y) acc = cadd(acc, v2);
+                    if (k + 3 < sg.y) acc = cadd(acc, v3);
                 }
-                for (int k = rg.z; k < rg.w; k += 4) {
-                    const T a0 = Av[k], a1 = Av[k + 1], a2 = Av[k + 2], a3 = Av[k + 3];
-                    acc += a0;
-                    acc += k + 1 < rg.w ? a1 : (T)0;
-                    acc += k + 2 < rg.w ? a2 : (T)0;
-                    acc += k + 3 < rg.w ? a3 : (T)0;
+                if (sg.z >= 0) {
+                    Tt[sg.z] = acc.x;
+                    Ut[sg.z] = acc.y;
                 }
-                const T lv = tlog<T>(acc < (T)1 ? (T)1 : acc);
+            }
+            group_sync<G>();
+            for (int ch = l; ch < (SKIP(6) ? 0 : a.P); ch += G) {
+                const T m = Ut[ch] + Tt[ch + 1];
+                const T lv = tlog<T>(m < (T)1 ? (T)1 : m);
                 if (a.fbkElems) fbk[ch] = lv;
                 if (active && a.fbankFlag) fo[ch] = lv;
             }
@@ -550,7 +588,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC>())) void k
 
         // ---- tile rows -> HBM (static block of every row; delta slots are written later)
         const long long row0 = ud.outRow + f0;
-        for (int i = tid; i < nf * a.vSize; i += kBlock) {
+        for (int i = tid; i < (SKIP(8) ? 0 : nf * a.vSize); i += kBlock) {
             const int r = i / a.vSize, c = i - r * a.vSize;
             a.out[(row0 + r) * a.step + c] = feat[i];
         }
@@ -799,90 +837,98 @@ __global__ void k_uttmeans(UttDesc *utts, int numUtts, const unsigned long long 
         if (e_ != hipSuccess) return (int)e_; \
     } while (0)
 
-template <typename T, int L, bool TLDS>
+template <typename T, int L, int PL, bool TLDS>
 static int launch_front_t(const FrontArgs<T> &a, int numBlocks, size_t lds, hipStream_t st)
 {
     static bool attrSet[16] = {};
     int dev = 0;
     MFCC_HIP_OK(hipGetDevice(&dev));
     if (dev < 16 && !attrSet[dev]) {
-        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, TLDS>),
+        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attrSet[dev] = true;
     }
-    hipLaunchKernelGGL((k_front<T, L, TLDS>), dim3(numBlocks), dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((k_front<T, L, PL, TLDS>), dim3(numBlocks), dim3(kBlock), lds, st, a);
     return (int)hipGetLastError();
 }
 
-template <typename T>
-static int launch_front_p(int log2nc, const void *args, int numBlocks, size_t lds, hipStream_t st)
+template <typename T, int L, int PL, bool TLDS>
+static int front_occ_t(size_t lds)
 {
+    int n = 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_front<T, L, PL, TLDS>, kBlock, lds) != hipSuccess)
+        return 0;
+    return n;
+}
+
+// Dispatch over (precision, log2 nc, points per lane, tables in LDS).  op 0: launch, op 1: occupancy.
+template <typename T, int L, int PL>
+static int front_do(int op, bool tl, const void *args, int numBlocks, size_t lds, hipStream_t st)
+{
+    if (op == 1) return tl ? front_occ_t<T, L, PL, true>(lds) : front_occ_t<T, L, PL, false>(lds);
     const FrontArgs<T> &a = *static_cast<const FrontArgs<T> *>(args);
-    const bool tl = a.tabElems > 0;
-    switch (log2nc) {
-#define MFCC_CASE(L)                                                         \
-    case L:                                                                  \
-        return tl ? launch_front_t<T, L, true>(a, numBlocks, lds, st)        \
-                  : launch_front_t<T, L, false>(a, numBlocks, lds, st);
-        MFCC_CASE(1) MFCC_CASE(2) MFCC_CASE(3) MFCC_CASE(4) MFCC_CASE(5) MFCC_CASE(6) MFCC_CASE(7)
-        MFCC_CASE(8) MFCC_CASE(9) MFCC_CASE(10) MFCC_CASE(11) MFCC_CASE(12) MFCC_CASE(13)
+    return tl ? launch_front_t<T, L, PL, true>(a, numBlocks, lds, st)
+              : launch_front_t<T, L, PL, false>(a, numBlocks, lds, st);
+}
+
+template <typename T>
+static int front_dispatch(int op, int log2nc, int pplog, bool tl, const void *args, int numBlocks,
+                          size_t lds, hipStream_t st)
+{
+    switch (log2nc * 8 + pplog) {
+#define MFCC_CASE(L, PL) \
+    case L * 8 + PL: return front_do<T, L, PL>(op, tl, args, numBlocks, lds, st);
+        MFCC_CASE(1, 4) MFCC_CASE(2, 4) MFCC_CASE(3, 4) MFCC_CASE(4, 4) MFCC_CASE(5, 4)
+        MFCC_CASE(6, 4) MFCC_CASE(7, 4) MFCC_CASE(8, 4) MFCC_CASE(9, 4) MFCC_CASE(10, 4)
+        MFCC_CASE(11, 4) MFCC_CASE(12, 4) MFCC_CASE(13, 4)
+        MFCC_CASE(6, 3) MFCC_CASE(7, 3) MFCC_CASE(8, 3) MFCC_CASE(9, 3) MFCC_CASE(10, 3) MFCC_CASE(11, 3)
+        MFCC_CASE(6, 2) MFCC_CASE(7, 2) MFCC_CASE(8, 2) MFCC_CASE(9, 2) MFCC_CASE(10, 2)
 #undef MFCC_CASE
     default: return -1;
     }
 }
 
-int launch_front(int precision, int log2nc, const void *args, int numBlocks, size_t ldsBytes,
+bool front_variant_exists(int log2nc, int pplog)
+{
+    if (pplog == 4) return log2nc >= 1 && log2nc <= kMaxLog2Nc;
+    if (pplog == 3) return log2nc >= 6 && log2nc <= 11;
+    if (pplog == 2) return log2nc >= 6 && log2nc <= 10;
+    return false;
+}
+
+int launch_front(int precision, int log2nc, int pplog, const void *args, int numBlocks, size_t ldsBytes,
                  void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (numBlocks <= 0) return 0;
-    return precision == 1 ? launch_front_p<double>(log2nc, args, numBlocks, ldsBytes, st)
-                          : launch_front_p<float>(log2nc, args, numBlocks, ldsBytes, st);
-}
-
-int front_groups(int log2nc)
-{
-    const int nc = 1 << log2nc;
-    const int g = nc >= 16 ? (nc / 16 > kBlock ? kBlock : nc / 16) : 1;
-    return kBlock / g;
-}
-
-int front_zpitch(int log2nc)
-{
-    const int nc = 1 << log2nc;
-    return (2 * (nc + nc / 16) + 3) & ~3;
-}
-
-template <typename T, int L, bool TLDS>
-static int front_occ_t(size_t lds)
-{
-    int n = 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, TLDS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_front<T, L, TLDS>, kBlock, lds) != hipSuccess)
-        return 0;
-    return n;
+    const bool tl = precision == 1 ? static_cast<const FrontArgs<double> *>(args)->tabElems > 0
+                                   : static_cast<const FrontArgs<float> *>(args)->tabElems > 0;
+    return precision == 1 ? front_dispatch<double>(0, log2nc, pplog, tl, args, numBlocks, ldsBytes, st)
+                          : front_dispatch<float>(0, log2nc, pplog, tl, args, numBlocks, ldsBytes, st);
 }
 
 // Workgroups of the static-feature kernel that the runtime says fit one CU (0 = unknown).
-int front_occupancy(int precision, int log2nc, bool tabLds, size_t ldsBytes)
+int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, size_t ldsBytes)
 {
-    switch (log2nc) {
-#define MFCC_CASE(L)                                                                            \
-    case L:                                                                                     \
-        return precision == 1                                                                   \
-                   ? (tabLds ? front_occ_t<double, L, true>(ldsBytes) : front_occ_t<double, L, false>(ldsBytes)) \
-                   : (tabLds ? front_occ_t<float, L, true>(ldsBytes) : front_occ_t<float, L, false>(ldsBytes));
-        MFCC_CASE(1) MFCC_CASE(2) MFCC_CASE(3) MFCC_CASE(4) MFCC_CASE(5) MFCC_CASE(6) MFCC_CASE(7)
-        MFCC_CASE(8) MFCC_CASE(9) MFCC_CASE(10) MFCC_CASE(11) MFCC_CASE(12) MFCC_CASE(13)
-#undef MFCC_CASE
-    default: return 0;
-    }
+    const int n = precision == 1 ? front_dispatch<double>(1, log2nc, pplog, tabLds, nullptr, 0, ldsBytes, nullptr)
+                                 : front_dispatch<float>(1, log2nc, pplog, tabLds, nullptr, 0, ldsBytes, nullptr);
+    return n < 0 ? 0 : n;
 }
 
-int front_waves_limit(int precision, int log2nc)
+int front_lanes(int log2nc, int pplog)
 {
-    return precision == 1 ? (log2nc <= 7 ? 2 : 1) : (log2nc <= 9 ? 3 : (log2nc <= 11 ? 2 : 1));
+    const int nc = 1 << log2nc;
+    const int ppl0 = 1 << (pplog < log2nc ? pplog : log2nc);
+    return nc / ppl0 > kBlock ? kBlock : nc / ppl0;
+}
+
+int front_groups(int log2nc, int pplog) { return kBlock / front_lanes(log2nc, pplog); }
+
+int front_waves_limit(int precision, int log2nc, int pplog)
+{
+    return front_waves_rule(precision == 1, log2nc, pplog);
 }
 
 int launch_regress(int precision, const void *args, int numTiles, void *stream)

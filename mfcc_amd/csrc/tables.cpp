@@ -62,28 +62,6 @@ int build_tables(const MFCCConfig &cfg, Tables &t)
         else
             t.loWt[k - 1] = (t.cf[0] - melk) / (t.cf[0] - t.mlo);
     }
-    // Gather form of the scatter in mfcc.c:159-162: channel b (1-based) receives (1 - loWt) of
-    // the bins whose lower channel is b-1 and loWt of the bins whose lower channel is b.  loChan
-    // is non-decreasing over the pass band, so both sets are contiguous bin ranges.
-    t.chanRange.assign(4 * (size_t)P, 0);
-    for (int b = 1; b <= P; ++b) {
-        int hi0 = -1, hi1 = -1, lo0 = -1, lo1 = -1;
-        for (int k = 0; k < half; ++k) {
-            if (t.loChan[k] == b - 1) {
-                if (hi0 < 0) hi0 = k;
-                hi1 = k + 1;
-            }
-            if (t.loChan[k] == b) {
-                if (lo0 < 0) lo0 = k;
-                lo1 = k + 1;
-            }
-        }
-        t.chanRange[4 * (b - 1) + 0] = hi0 < 0 ? 0 : hi0;
-        t.chanRange[4 * (b - 1) + 1] = hi0 < 0 ? 0 : hi1;
-        t.chanRange[4 * (b - 1) + 2] = lo0 < 0 ? 0 : lo0;
-        t.chanRange[4 * (b - 1) + 3] = lo0 < 0 ? 0 : lo1;
-    }
-
     // Hamming window: HTK GenHamWindow, w[i] = 0.54 - 0.46 cos(2 pi (i-1) / (W-1))
     t.window.resize(cfg.wlen);
     {
