@@ -96,8 +96,10 @@ __device__ __forceinline__ double sub_mul_exact(double x, double xp, double k)
 
 template <typename T>
 __device__ __forceinline__ T tlog(T x);
+// single precision: hardware log2 times ln 2 (absolute error below 1e-5 for the values that
+// occur here, |ln x| < 50), an order of magnitude inside the 1e-4 log-mel tolerance
 template <>
-__device__ __forceinline__ float tlog<float>(float x) { return logf(x); }
+__device__ __forceinline__ float tlog<float>(float x) { return __logf(x); }
 template <>
 __device__ __forceinline__ double tlog<double>(double x) { return log(x); }
 template <typename T>
@@ -223,9 +225,108 @@ __device__ __forceinline__ void unpack_tile(T *rows, const unsigned *raw, int ro
     }
 }
 
+// Fast form of the tile unpack for tiles whose first sample has a predecessor: the raw bytes were
+// copied so that the predecessor of sample 0 sits at byte 0 of `raw`, hence the 5 instants a lane
+// needs (predecessor + 4 samples) start on a dword boundary and every byte offset inside the
+// lane's register window is a compile-time constant.
+template <int BPS, int O, int NW>
+__device__ __forceinline__ int window_sample(const unsigned (&d)[NW])
+{
+    constexpr int w = O >> 2, sh = O & 3;
+    unsigned v;
+    if constexpr (sh + BPS <= 4)
+        v = d[w] >> (8 * sh);
+    else
+        v = __builtin_amdgcn_alignbyte(d[w + 1], d[w], (unsigned)sh);
+    if constexpr (BPS == 2)
+        return (int)(short)(v & 0xffffu);
+    else if constexpr (BPS == 3)
+        return ((int)(v << 8)) >> 8;
+    else
+        return (int)v;
+}
+
+template <typename T, bool EXACT, int CH, int BPS>
+__device__ __forceinline__ void unpack_tile_fast(T *rows, const unsigned *raw, int rowPitch, int V,
+                                                 int ns, const double *mean, double preK, int tid)
+{
+    using A = typename std::conditional<EXACT, double, float>::type;
+    constexpr int BPI = CH * BPS, NW = (5 * BPI + 3) / 4;
+    const A k = (A)preK;
+    const int nq = (ns + 3) >> 2;
+    A mu[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) mu[v] = (A)mean[v];
+    for (int q = tid; q < nq; q += kBlock) {
+        const int s0 = 4 * q;
+        const unsigned *src = raw + q * BPI; // byte 4 q BPI: predecessor of sample s0
+        unsigned d[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) d[i] = src[i];
+        A x[5][CH == 2 ? 4 : 1];
+        // unrolled by hand over the 5 instants: the offsets must be template arguments
+#define MFCC_INSTANT(i)                                                          \
+        {                                                                        \
+            const int c0 = window_sample<BPS, (i) * BPI, NW>(d);                 \
+            x[i][0] = (A)c0 - mu[0];                                             \
+            if constexpr (CH == 2) {                                             \
+                const int c1 = window_sample<BPS, (i) * BPI + BPS, NW>(d);       \
+                x[i][1] = (A)c1 - mu[1];                                         \
+                x[i][2] = (A)0.5 * ((A)c0 + (A)c1) - mu[2];                      \
+                x[i][3] = ((A)c0 - (A)c1) - mu[3];                               \
+            }                                                                    \
+        }
+        MFCC_INSTANT(0) MFCC_INSTANT(1) MFCC_INSTANT(2) MFCC_INSTANT(3) MFCC_INSTANT(4)
+#undef MFCC_INSTANT
+#pragma unroll
+        for (int v = 0; v < (CH == 2 ? 4 : 1); ++v) {
+            if (v < V) {
+                T y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    A r;
+                    if constexpr (EXACT)
+                        r = sub_mul_exact(x[i + 1][v], x[i][v], k);
+                    else
+                        r = x[i + 1][v] - k * x[i][v];
+                    y[i] = s0 + i < ns ? (T)r : (T)0; // keeps the zero tail behind the tile intact
+                }
+                T *dst = rows + v * rowPitch + s0;
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(y[0], y[1], y[2], y[3]);
+                } else {
+                    *reinterpret_cast<double2 *>(dst) = make_double2(y[0], y[1]);
+                    *reinterpret_cast<double2 *>(dst + 2) = make_double2(y[2], y[3]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int CH, int BPS>
+__device__ __forceinline__ void unpack_tile_fast_sel(bool exact, T *rows, const unsigned *raw,
+                                                     int rowPitch, int V, int ns, const double *mean,
+                                                     double preK, int tid)
+{
+    if constexpr (sizeof(T) == 8) {
+        unpack_tile_fast<T, true, CH, BPS>(rows, raw, rowPitch, V, ns, mean, preK, tid);
+    } else {
+        if (exact)
+            unpack_tile_fast<T, true, CH, BPS>(rows, raw, rowPitch, V, ns, mean, preK, tid);
+        else
+            unpack_tile_fast<T, false, CH, BPS>(rows, raw, rowPitch, V, ns, mean, preK, tid);
+    }
+}
+
 // Diagnostic build only (-DMFCC_STAMPS): per-phase cycle shares of the static-feature kernel,
 // summed over waves into FrontArgs::stamps.  Never compiled into the shipped library.
-#ifdef MFCC_STAMPS
+#if defined(MFCC_STAMPS) && defined(MFCC_SKIP_ONLY)
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#define STAMP_FLUSH
+#define SKIP(b) ((a.skip >> (b)) & 1)
+#elif defined(MFCC_STAMPS)
 #define STAMP_DECL unsigned long long st_last = 0, st_acc[12] = {}; (void)st_last;
 #define STAMP_START                                             \
     do {                                                        \
@@ -327,31 +428,55 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         const int ns = (nf - 1) * a.inc + a.wlen;                 // frame samples in the tile
         const int lead = (int)(first - first0);
 
-        // A1: tile bytes -> LDS, 16-byte aligned vector loads (each block holds >= 1 valid byte)
-        const unsigned char *gbase = a.pcm + ud.byteOff + first0 * bpi;
-        const unsigned long long gaddr = (unsigned long long)gbase;
-        const int mis = (int)(gaddr & 15ull);
-        const uint4 *src = reinterpret_cast<const uint4 *>(gaddr - mis);
-        const int nvec = (mis + (ns + lead) * bpi + 15) >> 4;
-        if (!SKIP(7))
-            for (int i = tid; i < nvec; i += kBlock) reinterpret_cast<uint4 *>(raw)[i] = src[i];
-        __syncthreads();
-        STAMP(0);
-
-        // A2: unpack / derive rows / remove mean / pre-emphasise (see unpack_tile)
-        if (!SKIP(0)) {
-            const bool exact = sizeof(T) == 8 || a.zcFlag != 0;
-            if (a.channels == 2) {
-                if (exact)
-                    unpack_tile<T, true, 2>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
-                else
-                    unpack_tile<T, false, 2>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
-            } else {
-                if (exact)
-                    unpack_tile<T, true, 1>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
-                else
-                    unpack_tile<T, false, 1>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
+        // A: tile bytes -> LDS -> derived, mean-free, pre-emphasised rows (see unpack_tile*).
+        const bool exact = sizeof(T) == 8 || a.zcFlag != 0;
+        const bool fastA = first > 0 && (a.bps == 2 || a.bps == 3);
+        if (fastA) {
+            // Copy starts exactly at the predecessor of the tile's first sample (16-byte vector
+            // loads from a possibly unaligned address), the last partial vector byte by byte so
+            // that nothing behind the tile's bytes is touched.
+            typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
+            const unsigned char *g0 = a.pcm + ud.byteOff + first0 * bpi;
+            const int nbytes = (ns + 1) * bpi, nfull = nbytes >> 4;
+            if (!SKIP(7)) {
+                for (int i = tid; i < nfull; i += kBlock) {
+                    const u4u vv4 = reinterpret_cast<const u4u *>(g0)[i];
+                    reinterpret_cast<uint4 *>(raw)[i] = make_uint4(vv4.x, vv4.y, vv4.z, vv4.w);
+                }
+                for (int i = (nfull << 4) + tid; i < nbytes; i += kBlock)
+                    reinterpret_cast<unsigned char *>(raw)[i] = g0[i];
             }
+            __syncthreads();
+            STAMP(0);
+            if (!SKIP(0)) {
+                if (a.channels == 2) {
+                    if (a.bps == 2)
+                        unpack_tile_fast_sel<T, 2, 2>(exact, rows, raw, a.rowPitch, a.V, ns, ud.mean, a.preK, tid);
+                    else
+                        unpack_tile_fast_sel<T, 2, 3>(exact, rows, raw, a.rowPitch, a.V, ns, ud.mean, a.preK, tid);
+                } else {
+                    if (a.bps == 2)
+                        unpack_tile_fast_sel<T, 1, 2>(exact, rows, raw, a.rowPitch, a.V, ns, ud.mean, a.preK, tid);
+                    else
+                        unpack_tile_fast_sel<T, 1, 3>(exact, rows, raw, a.rowPitch, a.V, ns, ud.mean, a.preK, tid);
+                }
+            }
+        } else {
+            // General form (first tile of an utterance, 32-bit samples): 16-byte aligned vector
+            // loads (each holds >= 1 valid byte, so it stays inside the buffer's pages), samples
+            // picked at run-time byte offsets, double arithmetic.
+            const unsigned char *gbase = a.pcm + ud.byteOff + first0 * bpi;
+            const unsigned long long gaddr = (unsigned long long)gbase;
+            const int mis = (int)(gaddr & 15ull);
+            const uint4 *src = reinterpret_cast<const uint4 *>(gaddr - mis);
+            const int nvec = (mis + (ns + lead) * bpi + 15) >> 4;
+            for (int i = tid; i < nvec; i += kBlock) reinterpret_cast<uint4 *>(raw)[i] = src[i];
+            __syncthreads();
+            STAMP(0);
+            if (a.channels == 2)
+                unpack_tile<T, true, 2>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
+            else
+                unpack_tile<T, true, 1>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
         }
         for (int s = tid; s < a.rowTail; s += kBlock)
             for (int v = 0; v < a.V; ++v) rows[v * a.rowPitch + ns + s] = (T)0;
@@ -362,7 +487,9 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         for (int base = 0; base < nItems; base += GROUPS) {
             const int item = base + grp;
             const bool active = item < nItems;
-            const int fr = active ? item / a.V : 0, vv = active ? item - fr * a.V : 0;
+            const int it = active ? item : 0; // V is 1..4: no general division needed
+            const int fr = a.V == 1 ? it : (a.V == 2 ? it >> 1 : (a.V == 4 ? it >> 2 : it / 3));
+            const int vv = it - fr * a.V;
             const T *x = rows + vv * a.rowPitch + fr * a.inc;
             T *Zt = zbuf + grp * a.zPitch;
             cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
@@ -588,9 +715,14 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 
         // ---- tile rows -> HBM (static block of every row; delta slots are written later)
         const long long row0 = ud.outRow + f0;
-        for (int i = tid; i < (SKIP(8) ? 0 : nf * a.vSize); i += kBlock) {
-            const int r = i / a.vSize, c = i - r * a.vSize;
-            a.out[(row0 + r) * a.step + c] = feat[i];
+        if (a.step == a.vSize) { // no delta slots: the tile's rows are one contiguous run
+            T *dst = a.out + row0 * a.step;
+            for (int i = tid; i < (SKIP(8) ? 0 : nf * a.vSize); i += kBlock) dst[i] = feat[i];
+        } else {
+            for (int r = tid >> 6; r < (SKIP(8) ? 0 : nf); r += kBlock / 64) {
+                T *dst = a.out + (row0 + r) * a.step;
+                for (int c = tid & 63; c < a.vSize; c += 64) dst[c] = feat[r * a.vSize + c];
+            }
         }
         STAMP(9);
     }
