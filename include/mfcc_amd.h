@@ -126,6 +126,13 @@ int MFCCWriteFeatures(const char *path, const double *data, long numFrames, int 
 int MFCCWavInfo(const void *wavFile, size_t wavLen, int *channels, int *sampleRate,
                 int *bytesPerSample, long *numSamples, size_t *dataOffset);
 
+/* The one-time host tables without a device: what InitFBank (mfcc.c:39-122) and GenHamWindow
+ * (main.c:171) compute, plus the two pass-band lines mfcc.c:74-75 print.  cf[bankNum+1],
+ * loChan[fftN/2], loWt[fftN/2] (entry [k-1] = the reference's 1-based [k]), window[wlen]; any
+ * pointer may be NULL. */
+int MFCCHostTables(const MFCCConfig *cfg, int *fftN, int *klo, int *khi, double *cf, int *loChan,
+                   double *loWt, double *window, char *passband, size_t cap);
+
 /* ------------------------------------------------------------------------------------------
  * Device-resident batched path: PCM bytes already in HBM, features left in HBM.
  * ---------------------------------------------------------------------------------------- */
@@ -166,6 +173,14 @@ int MFCCPlanCreateShard(MFCCContext *ctx, int channels, int bytesPerSample, int6
                         int64_t frameBegin, int64_t frameEnd, const int64_t *chanSum2,
                         MFCCPlan **plan);
 void MFCCPlanDestroy(MFCCPlan *plan);
+
+/* The arithmetic of MFCCPlanCreateShard without a device (host-only, usable for planning a
+ * distribution): which instants a rank must hold for frames [frameBegin, frameEnd) and where its
+ * own rows sit in its output matrix.  lead = 1 when the first instant is only the pre-emphasis
+ * predecessor of the second.  Any out-pointer may be NULL. */
+int MFCCShardGeometry(const MFCCConfig *cfg, int64_t totalSamples, int64_t frameBegin,
+                      int64_t frameEnd, int64_t *sampleBegin, int64_t *sampleCount,
+                      int64_t *totalRows, int64_t *ownedRowBegin, int64_t *ownedRows, int *lead);
 
 int64_t MFCCPlanTotalRows(const MFCCPlan *plan);
 int64_t MFCCPlanRowOffset(const MFCCPlan *plan, int utt);

@@ -64,9 +64,9 @@ _lib = None
 EXPORTS = [
     "MFCCLastError", "MFCCFree", "MFCCConfigDefaults", "MFCCConfigFromIni", "MFCCNumFrames",
     "MFCCFeatureDim", "MFCCStep", "MFCCWapper", "MFCCWapperMem", "MFCCWapperList",
-    "MFCCWriteFeatures", "MFCCWavInfo", "MFCCContextCreate", "MFCCContextDestroy",
+    "MFCCWriteFeatures", "MFCCWavInfo", "MFCCHostTables", "MFCCContextCreate", "MFCCContextDestroy",
     "MFCCContextPassbandText", "MFCCContextTables", "MFCCPlanCreate", "MFCCPlanCreateShard",
-    "MFCCPlanDestroy", "MFCCPlanTotalRows", "MFCCPlanRowOffset", "MFCCPlanNumFrames",
+    "MFCCPlanDestroy", "MFCCShardGeometry", "MFCCPlanTotalRows", "MFCCPlanRowOffset", "MFCCPlanNumFrames",
     "MFCCPlanSampleBegin", "MFCCPlanSampleCount", "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows",
     "MFCCExtractDevice", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
     "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm",
@@ -104,6 +104,8 @@ def lib():
     L.MFCCWriteFeatures.argtypes = [C.c_char_p, dp, C.c_long, C.c_int, C.c_int]
     L.MFCCWavInfo.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                               C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_size_t)]
+    L.MFCCHostTables.argtypes = [cfgp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), dp,
+                                 C.POINTER(C.c_int), dp, dp, C.c_char_p, C.c_size_t]
     L.MFCCContextCreate.argtypes = [cfgp, C.c_int, C.POINTER(vp)]
     L.MFCCContextDestroy.argtypes = [vp]
     L.MFCCContextDestroy.restype = None
@@ -115,6 +117,8 @@ def lib():
                                       C.POINTER(vp)]
     L.MFCCPlanDestroy.argtypes = [vp]
     L.MFCCPlanDestroy.restype = None
+    L.MFCCShardGeometry.argtypes = [cfgp, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, i64p, i64p,
+                                    i64p, C.POINTER(C.c_int)]
     for name in ("MFCCPlanTotalRows", "MFCCPlanSampleBegin", "MFCCPlanSampleCount",
                  "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows"):
         getattr(L, name).argtypes = [vp]
@@ -256,6 +260,35 @@ def wapper_list(ini_path):
     if rc < 0:
         _check(rc)
     return rc
+
+
+def host_tables(cfg):
+    """MFCCHostTables as a dict: the filterbank / window tables computed on the host, no device."""
+    fft_n, klo, khi = C.c_int(), C.c_int(), C.c_int()
+    buf = C.create_string_buffer(256)
+    _check(lib().MFCCHostTables(C.byref(cfg), C.byref(fft_n), C.byref(klo), C.byref(khi), None, None,
+                                None, None, buf, 256))
+    half, P = fft_n.value // 2, cfg.bankNum
+    cf, lo_wt, win = np.zeros(P + 1), np.zeros(half), np.zeros(cfg.wlen)
+    lo_chan = np.zeros(half, dtype=np.int32)
+    dp = C.POINTER(C.c_double)
+    _check(lib().MFCCHostTables(C.byref(cfg), None, None, None, cf.ctypes.data_as(dp),
+                                lo_chan.ctypes.data_as(C.POINTER(C.c_int)), lo_wt.ctypes.data_as(dp),
+                                win.ctypes.data_as(dp), None, 0))
+    return dict(fftN=fft_n.value, klo=klo.value, khi=khi.value, cf=cf, loChan=lo_chan, loWt=lo_wt,
+                window=win, text=buf.value.decode())
+
+
+def shard_geometry(cfg, total_samples, frame_begin, frame_end):
+    """MFCCShardGeometry as a dict (no device needed)."""
+    vals = [C.c_int64() for _ in range(5)]
+    lead = C.c_int()
+    _check(lib().MFCCShardGeometry(C.byref(cfg), total_samples, frame_begin, frame_end,
+                                   *[C.byref(x) for x in vals], C.byref(lead)))
+    keys = ("sample_begin", "sample_count", "total_rows", "owned_row_begin", "owned_rows")
+    out = {k: x.value for k, x in zip(keys, vals)}
+    out["lead"] = lead.value
+    return out
 
 
 class Context:

@@ -152,6 +152,32 @@ extern "C" int MFCCContextTables(const MFCCContext *c, int *fftN, int *klo, int 
     return MFCC_OK;
 }
 
+extern "C" int MFCCHostTables(const MFCCConfig *cfgIn, int *fftN, int *klo, int *khi, double *cf,
+                              int *loChan, double *loWt, double *window, char *passband, size_t cap)
+{
+    if (!cfgIn) return set_error("NULL argument"), MFCC_E_ARG;
+    MFCCConfig cfg = *cfgIn;
+    if (cfg.fbankFlag) {
+        cfg.MFCCNum = cfg.bankNum;
+        cfg.MFCC0thFlag = 0;
+    }
+    int rc = validate_config(cfg);
+    if (rc) return rc;
+    Tables t;
+    if ((rc = build_tables(cfg, t))) return rc;
+    if (fftN) *fftN = t.fftN;
+    if (klo) *klo = t.klo;
+    if (khi) *khi = t.khi;
+    if (cf) std::copy(t.cf.begin(), t.cf.end(), cf);
+    if (loChan) std::copy(t.loChan.begin(), t.loChan.end(), loChan);
+    if (loWt) std::copy(t.loWt.begin(), t.loWt.end(), loWt);
+    if (window) std::copy(t.window.begin(), t.window.end(), window);
+    if (passband)
+        snprintf(passband, cap, "FFT passband %d to %d out of 1 to %d\nMel passband %f to %f\n", t.klo,
+                 t.khi, t.nc, t.mlo, t.mhi); /* mfcc.c:74-75 */
+    return MFCC_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // plans
 // ------------------------------------------------------------------------------------------
@@ -396,6 +422,32 @@ extern "C" int MFCCPlanCreate(MFCCContext *c, int channels, int bytesPerSample, 
     return MFCC_OK;
 }
 
+extern "C" int MFCCShardGeometry(const MFCCConfig *cfg, int64_t totalSamples, int64_t frameBegin,
+                                 int64_t frameEnd, int64_t *sampleBegin, int64_t *sampleCount,
+                                 int64_t *totalRows, int64_t *ownedRowBegin, int64_t *ownedRows,
+                                 int *lead)
+{
+    if (!cfg || totalSamples < 0 || cfg->wlen < 1 || cfg->inc < 1)
+        return set_error("bad argument to MFCCShardGeometry"), MFCC_E_ARG;
+    const int64_t W = cfg->wlen, H = cfg->inc;
+    const int64_t total = totalSamples < W ? 0 : (totalSamples - (W - H)) / H;
+    frameBegin = std::max<int64_t>(0, std::min(frameBegin, total));
+    frameEnd = std::max(frameBegin, std::min(frameEnd, total));
+    // Regress reads delwin frames on each side; every further delta order reads delwin more
+    const int64_t halo = (int64_t)(cfg->regreOrder - 1) * cfg->delwin;
+    const int64_t eb = std::max<int64_t>(0, frameBegin - halo), ee = std::min(total, frameEnd + halo);
+    const bool empty = frameEnd == frameBegin;
+    const int ld = (!empty && eb * H > 0) ? 1 : 0; // one lead instant for pre-emphasis
+    const int64_t sb = empty ? 0 : eb * H - ld;
+    if (sampleBegin) *sampleBegin = sb;
+    if (sampleCount) *sampleCount = empty ? 0 : (ee - 1) * H + W - sb;
+    if (totalRows) *totalRows = empty ? 0 : ee - eb;
+    if (ownedRowBegin) *ownedRowBegin = empty ? 0 : frameBegin - eb;
+    if (ownedRows) *ownedRows = frameEnd - frameBegin;
+    if (lead) *lead = ld;
+    return MFCC_OK;
+}
+
 extern "C" int MFCCPlanCreateShard(MFCCContext *c, int channels, int bytesPerSample,
                                    int64_t totalSamples, int64_t frameBegin, int64_t frameEnd,
                                    const int64_t *chanSum2, MFCCPlan **out)
@@ -408,12 +460,6 @@ extern "C" int MFCCPlanCreateShard(MFCCContext *c, int channels, int bytesPerSam
     if (c->cfg.vecNum > rows) return set_error("vecnum %d > num_channels %d", c->cfg.vecNum, channels), MFCC_E_VECNUM;
     if (c->cfg.zeroMeanSigFlag && !chanSum2)
         return set_error("zeroMeanSigFlag needs chanSum2 for a shard plan"), MFCC_E_ARG;
-    const int64_t W = c->cfg.wlen, H = c->cfg.inc;
-    const int64_t total = totalSamples < W ? 0 : (totalSamples - (W - H)) / H;
-    frameBegin = std::max<int64_t>(0, std::min(frameBegin, total));
-    frameEnd = std::max(frameBegin, std::min(frameEnd, total));
-    const int64_t halo = (int64_t)(c->cfg.regreOrder - 1) * c->cfg.delwin;
-    const int64_t eb = std::max<int64_t>(0, frameBegin - halo), ee = std::min(total, frameEnd + halo);
     std::unique_ptr<MFCCPlan> p(new MFCCPlan);
     p->ctx = c;
     p->shard = true;
@@ -423,24 +469,23 @@ extern "C" int MFCCPlanCreateShard(MFCCContext *c, int channels, int bytesPerSam
     p->utts.resize(1);
     UttDesc &d = p->utts[0];
     memset(&d, 0, sizeof d);
-    const bool empty = frameEnd == frameBegin;
-    const int lead = (!empty && eb * H > 0) ? 1 : 0;
-    p->sampleBegin = empty ? 0 : eb * H - lead;
-    p->sampleCount = empty ? 0 : (ee - 1) * H + W - p->sampleBegin;
+    int64_t rowsTotal = 0;
+    int lead = 0;
+    int rc = MFCCShardGeometry(&c->cfg, totalSamples, frameBegin, frameEnd, &p->sampleBegin,
+                               &p->sampleCount, &rowsTotal, &p->ownedRowBegin, &p->ownedRows, &lead);
+    if (rc) return rc;
     if (p->sampleCount > 0x7fffffffLL) return set_error("shard longer than 2^31 instants"), MFCC_E_ARG;
     d.byteOff = 0;
     d.outRow = 0;
     d.numInstants = (int32_t)p->sampleCount;
-    d.numFrames = empty ? 0 : (int32_t)(ee - eb);
+    d.numFrames = (int32_t)rowsTotal;
     d.lead = lead;
-    d.ownBegin = empty ? 0 : (int32_t)(frameBegin - eb);
-    d.ownCount = (int32_t)(frameEnd - frameBegin);
+    d.ownBegin = (int32_t)p->ownedRowBegin;
+    d.ownCount = (int32_t)p->ownedRows;
     if (c->cfg.zeroMeanSigFlag && totalSamples > 0)
         for (int r = 0; r < 4; ++r) d.mean[r] = (double)chanSum2[r] / (2.0 * (double)totalSamples);
     p->totalRows = d.numFrames;
-    p->ownedRowBegin = d.ownBegin;
-    p->ownedRows = d.ownCount;
-    int rc = finish_plan(p.get());
+    rc = finish_plan(p.get());
     if (rc) {
         MFCCPlanDestroy(p.release());
         return rc;

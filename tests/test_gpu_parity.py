@@ -1,0 +1,312 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+libmfcc_amd.so, against the CPU oracle on the same seeded inputs, against the committed golden
+fixtures, and -- at the benchmark's full sizes -- through size-independent properties.
+
+Tolerances (single precision kernels, the shipped default): log-mel and log-energy 1e-4 absolute,
+cepstra / C0 1e-5 relative to the largest cepstral magnitude, ZCR exact, brightness / sub-band
+fractions 1e-5 absolute; deltas inherit the tolerance of their static column; z-normalised
+columns 2e-3 absolute (errors are divided by the column's standard deviation).  Double precision
+kernels must agree to 1e-9.  Frame counts, row layout and indexing must be exact."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import mfcc_amd as ma
+from mfcc_amd.presets import CONFIGS
+from util import assert_static_close, column_kinds, run_product_batch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _pcm(n, ch, bps, seed, sr, tone=440):
+    return ma.synth_pcm(n, ch, bps, seed=0x5EED0000 + seed, sample_rate=sr, tone_hz=tone)
+
+
+def _layout(kw):
+    return (1 if kw["vecNum"] == 1 else 2), (2 if kw["sampleRate"] == 16000 else 3)
+
+
+def _compare(got, ref, kw, f64):
+    """Static block by kind; delta blocks with the same per-kind tolerance; everything loosened
+    to 2e-3 when the matrix was z-normalised."""
+    assert got.shape == ref.shape
+    if kw.get("znormFlag", 0):
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        fin = np.isfinite(ref)
+        tol = 1e-8 if f64 else 2e-3
+        assert np.max(np.abs(np.where(fin, got - ref, 0.0)), initial=0.0) < tol
+        return
+    vs = len(column_kinds(kw)) * kw.get("vecNum", 1)
+    for o in range(kw.get("regreOrder", 1)):
+        assert_static_close(got[:, o * vs:(o + 1) * vs], ref[:, o * vs:(o + 1) * vs], kw, f64, delta=o > 0)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c1a", "c1b", "c5"])
+def test_named_configs_match_oracle(oracle, name, precision):
+    kw = CONFIGS[name]
+    ch, bps = _layout(kw)
+    n = kw["sampleRate"] + 123  # ~1 s: several tiles, first (general) and later (fast) unpack paths
+    pcm = _pcm(n, ch, bps, 7, kw["sampleRate"])
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, ch, bps)
+    f64 = precision == "f64"
+    cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+    got = run_product_batch(ma, cfg, [pcm.tobytes()], ch, bps)[0]
+    _compare(got, ref, kw, f64)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))))
+def test_golden_fixtures(path):
+    z = np.load(path)
+    kw = json.loads(str(z["config"]))
+    ch, bps = int(z["channels"]), int(z["bytes_per_sample"])
+    for f64 in (False, True):
+        cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+        got = run_product_batch(ma, cfg, [z["pcm"].tobytes()], ch, bps)[0]
+        _compare(got, z["expected"], kw, f64)
+
+
+@pytest.mark.parametrize("wlen", [3, 4, 5, 8, 9, 16, 17, 33, 64, 100, 129, 200, 256, 400, 513, 1024,
+                                  1200, 2048, 3000, 4096, 5000, 8192, 10000, 16384])
+def test_every_fft_size(oracle, wlen):
+    """fftN from 4 to 16384 (every kernel instantiation), odd and even inc."""
+    inc = max(1, wlen // 3) | 1 if wlen % 2 else max(1, wlen // 2)
+    kw = dict(sampleRate=16000, lowpassfre=-1, hipassfre=-1, preemphasise=0.97, wlen=wlen, inc=inc,
+              vecNum=1, fbankFlag=1, bankNum=min(12, max(1, wlen // 4)), energyFlag=1,
+              zeroCrossingFlag=1, brightFlag=1)
+    n = wlen + 9 * inc + (inc - 1)  # exactly 10 frames, the tail is dropped
+    pcm = _pcm(n, 1, 2, wlen, 16000, tone=0)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
+    assert ref.shape[0] == 10
+    for f64 in (False, True):
+        if f64 and wlen > 8192:
+            continue
+        cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+        got = run_product_batch(ma, cfg, [pcm.tobytes()], 1, 2)[0]
+        _compare(got, ref, kw, f64)
+
+
+def test_ragged_batch_and_edge_lengths(oracle):
+    """Empty, shorter than a window, exactly one window, one sample short of two frames, long."""
+    kw = CONFIGS["c3"]
+    lens = [0, 1, 399, 400, 559, 560, 561, 5000, 16000, 401, 33333]
+    pcms = [_pcm(n, 1, 2, 100 + i, 16000) for i, n in enumerate(lens)]
+    cfg = ma.make_config(**kw)
+    got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 1, 2)
+    ocfg = oracle.make_config(**kw)
+    for n, p, g in zip(lens, pcms, got):
+        assert g.shape[0] == oracle.num_frames(n, 400, 160) == ma.num_frames(n, 400, 160)
+        if g.shape[0] > 1:
+            _compare(g, oracle.extract_pcm_bytes(ocfg, p, 1, 2), kw, False)
+        elif g.shape[0] == 1:  # z-norm of a single frame is 0/0 in both
+            assert np.all(np.isnan(g))
+
+
+@pytest.mark.parametrize("ch,bps", [(1, 2), (2, 2), (1, 3), (2, 3), (1, 4), (2, 4)])
+@pytest.mark.parametrize("shift", [0, 1, 2, 3, 6])
+def test_pcm_layouts_and_misaligned_offsets(oracle, ch, bps, shift):
+    """Every sample size / channel count, with the utterance starting at odd byte offsets."""
+    kw = dict(CONFIGS["c2"], vecNum=ch, zeroCrossingFlag=1)
+    n = 3000
+    if bps == 4:
+        x = np.frombuffer(_pcm(n, ch, 3, 40 + shift, 16000).tobytes(), dtype=np.uint8).reshape(-1, 3)
+        pcm = np.concatenate([np.full((x.shape[0], 1), 7, np.uint8), x], axis=1).reshape(-1)  # x * 256 + 7
+    else:
+        pcm = _pcm(n, ch, bps, 40 + shift, 16000)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, ch, bps)
+    import torch
+    cfg = ma.make_config(**kw)
+    ctx = ma.Context(cfg, 0)
+    buf = np.zeros(pcm.size + 64, dtype=np.uint8)
+    buf[shift:shift + pcm.size] = pcm
+    plan = ma.Plan(ctx, ch, bps, [shift], [n])
+    out = plan.extract(torch.from_numpy(buf).cuda())
+    torch.cuda.synchronize()
+    _compare(out.double().cpu().numpy(), ref, kw, False)
+
+
+def test_zero_mean_and_stereo_rows(oracle):
+    kw = dict(CONFIGS["c1b"], zeroMeanSigFlag=1, preemphasise=0.95)  # vecNum 4: L, R, mid, side
+    pcm = _pcm(30000, 2, 3, 11, 44100)
+    x = np.frombuffer(pcm.tobytes(), dtype=np.uint8).astype(np.int64).reshape(-1, 2, 3)
+    dc = (x[..., 0] | (x[..., 1] << 8) | (x[..., 2] << 16))
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 2, 3)
+    for f64 in (False, True):
+        cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+        got = run_product_batch(ma, cfg, [pcm.tobytes()], 2, 3)[0]
+        _compare(got, ref, kw, f64)
+    assert dc.shape[0] == 30000
+
+
+def test_fft_length_debug_columns(oracle):
+    kw = dict(CONFIGS["c2"], fftLength=7, brightFlag=1, subBandEFlag=3)
+    pcm = _pcm(4000, 1, 2, 12, 16000)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
+    got = run_product_batch(ma, ma.make_config(**kw), [pcm.tobytes()], 1, 2)[0]
+    _compare(got, ref, kw, False)
+
+
+def test_silence_matches_reference_semantics(oracle):
+    """Digital silence: log-mel floored to 0, log(te) = -inf, brightness / sub-bands NaN, deltas of
+    those NaN (main.c:243 has no floor)."""
+    kw = dict(CONFIGS["c1a"])
+    pcm = np.zeros(20000 * 2 * 3, dtype=np.uint8)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 2, 3)
+    got = run_product_batch(ma, ma.make_config(**kw), [pcm.tobytes()], 2, 3)[0]
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    assert np.all(got[fin] == ref[fin])
+
+
+def test_zcr_is_exact_on_near_cancelling_samples(oracle):
+    """x[i] close to k*x[i-1]: the sign of the pre-emphasised sample decides a zero crossing; the
+    kernel's separately rounded double arithmetic must reproduce the reference's sign."""
+    kw = dict(CONFIGS["c2"], zeroCrossingFlag=1)
+    rng = np.random.default_rng(5)
+    base = rng.integers(100, 30000, size=6000)
+    x = np.empty(6000, dtype=np.int16)
+    x[0::2] = base[0::2] // 100 * 100
+    x[1::2] = (x[0::2].astype(np.int64) * 97) // 100  # x[i] = 0.97 x[i-1] exactly in integers
+    pcm = x.view(np.uint8)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
+    got = run_product_batch(ma, ma.make_config(**kw), [pcm.tobytes()], 1, 2)[0]
+    assert np.array_equal(got[:, 40], ref[:, 40].astype(np.float32).astype(np.float64))
+
+
+def test_wapper_entry_points_and_writers(oracle, tmp_path):
+    """MFCCWapper / MFCCWapperMem / MFCCWapperList end to end: files in, files out."""
+    kw = dict(CONFIGS["c3"])
+    pcm = _pcm(8000, 1, 2, 21, 16000)
+    wav = tmp_path / "a.wav"
+    wav.write_bytes(ma.wav_bytes(pcm, 1, 2, 16000, extra_chunk=(b"LIST", b"info")))
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
+    cfg = ma.make_config(saveType=ma.SAVE_N, **kw)
+    out = tmp_path / "a.npy"
+    feat = ma.wapper(cfg, str(wav), str(out))
+    _compare(feat, ref, kw, False)
+    assert np.array_equal(np.load(out), feat)
+    feat2 = ma.wapper_mem(cfg, wav.read_bytes())
+    assert np.array_equal(feat, feat2)
+    with pytest.raises(ma.MFCCError) as e:
+        ma.wapper(ma.make_config(**dict(kw, sampleRate=8000)), str(wav))
+    assert e.value.code == ma.E_SAMPLE_RATE
+    with pytest.raises(ma.MFCCError) as e:
+        ma.wapper(ma.make_config(**dict(kw, vecNum=2)), str(wav))
+    assert e.value.code == ma.E_VECNUM
+    # whole-run entry point with a list of three files, one of them unreadable
+    pcm2 = _pcm(5000, 1, 2, 22, 16000)
+    (tmp_path / "b.wav").write_bytes(ma.wav_bytes(pcm2, 1, 2, 16000))
+    lst = tmp_path / "list.txt"
+    lst.write_text("%s\t%s\n%s\t%s\n%s\t%s\n\nignored\tafter blank line\n" % (
+        wav, tmp_path / "a.txt", tmp_path / "nope.wav", tmp_path / "nope.txt", tmp_path / "b.wav", tmp_path / "b.txt"))
+    ini = tmp_path / "config.ini"
+    ini.write_text("[Frame];\nsampleRate = 16000 ;\nhipassfre = 8000 ;\nlowpassfre = 64 ;\npreemphasise = 0.97 ;\n"
+                   "wlen = 400 ;\ninc = 160 ;\nsaveType = e ;\nvecNum = 1 ;\nfileList = %s ;\n[MFCC];\n"
+                   "fbankFlag = 0 ;\nbankNum = 26 ;\nMFCCNum = 13 ;\nMFCC0thFlag = 1 ;\n[Others];\n"
+                   "energyFlag = 1 ;\nzeroCrossingFlag = 0 ;\nbrightFlag = 0 ;\nsubBandEFlag = 0 ;\n"
+                   "fftLength = 0 ;\n[Regression];\nregreOrder = 3 ;\ndelwin = 2 ;\nznormFlag = 1 ;\n"
+                   "[IO];\nnumThreads = 2 ;\n" % lst)
+    os.environ["MFCC_QUIET"] = "1"
+    assert ma.wapper_list(str(ini)) == 1  # one failed file, the run goes on
+    for name, p in (("a.txt", pcm), ("b.txt", pcm2)):
+        rows = [[float(v) for v in line.split("\t")[:-1]] for line in open(tmp_path / name)]
+        r = oracle.extract_pcm_bytes(oracle.make_config(**kw), p, 1, 2)
+        got = np.array(rows)
+        assert got.shape == r.shape
+        _compare(got, r, kw, False)
+        assert open(tmp_path / name).readline().endswith("\t\n")  # main.c:277-278 layout
+    assert not (tmp_path / "nope.txt").exists()
+
+
+@pytest.mark.parametrize("name,n,ch,bps", [("c5", 60000, 2, 3), ("c3", 20000, 1, 2)])
+def test_frame_sharded_recording_matches_whole(oracle, name, n, ch, bps):
+    """Shard plans (halo frames, lead instant, split z-norm) for 3 ranks emulated on one GPU."""
+    import torch
+    from mfcc_amd import sharding
+    kw = dict(CONFIGS[name], zeroMeanSigFlag=1)
+    pcm = _pcm(n, ch, bps, 31, kw["sampleRate"])
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, ch, bps)
+    cfg = ma.make_config(**kw)
+    ctx = ma.Context(cfg, 0)
+    dev = torch.from_numpy(pcm).cuda()
+    total = ma.num_frames(n, kw["wlen"], kw["inc"])
+    world, bpi = 3, ch * bps
+    ranges = sharding.frame_ranges(total, world)
+    # whole-recording channel sums from per-rank partial sums (any partition of the instants)
+    cuts = [0, n // 3, n // 2, n]
+    parts = [ma.channel_sums(ctx, dev, ch, bps, cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+    sums2 = sum(parts).cpu().numpy()
+    x = np.frombuffer(pcm.tobytes(), dtype=np.uint8).astype(np.int64).reshape(-1, ch, bps)
+    v = sum(x[..., k] << (8 * k) for k in range(bps))
+    v = np.where(v >= 1 << (8 * bps - 1), v - (1 << (8 * bps)), v)
+    L = int(v[:, 0].sum())
+    R = int(v[:, 1].sum()) if ch == 2 else 0
+    assert list(sums2) == [2 * L, 2 * R, L + R, 2 * (L - R)]
+    plans, outs, sums = [], [], []
+    for fb, fe in ranges:
+        g = ma.shard_geometry(cfg, n, fb, fe)
+        shard = dev[g["sample_begin"] * bpi:(g["sample_begin"] + g["sample_count"]) * bpi].clone()
+        plan = ma.Plan(ctx, ch, bps, shard=(n, fb, fe, sums2))
+        out = plan.extract(shard)
+        plans.append(plan)
+        outs.append(out)
+        sums.append(plan.shard_column_sums(out))
+    tot = sums[0] + sums[1] + sums[2]  # rank-ordered sum, as sharding.combine_sums does
+    pieces = []
+    for plan, out in zip(plans, outs):
+        plan.shard_normalize(out, tot)
+        pieces.append(out[plan.owned_row_begin:plan.owned_row_begin + plan.owned_rows])
+    torch.cuda.synchronize()
+    got = torch.cat(pieces).double().cpu().numpy()
+    _compare(got, ref, kw, False)
+
+
+def test_batch_order_and_shift_invariance_at_full_size():
+    """Benchmark-size properties (16 kHz, 10 s utterances, 40-bin log-mel): (1) an utterance's rows
+    do not depend on its position in the batch or on its neighbours; (2) delaying the signal by
+    one hop shifts the rows by one frame (pre-emphasis off, so no boundary effect)."""
+    import torch
+    kw = dict(CONFIGS["c2"], preemphasise=0.0)
+    n, U = 160000, 64
+    pcms = [_pcm(n, 1, 2, 500 + u, 16000, tone=0) for u in range(U)]
+    cfg = ma.make_config(**kw)
+    a = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 1, 2)
+    perm = np.random.default_rng(1).permutation(U)
+    b = run_product_batch(ma, cfg, [pcms[i].tobytes() for i in perm], 1, 2)
+    for j, i in enumerate(perm):
+        assert np.array_equal(a[i], b[j])
+    assert a[0].shape == (998, 40)
+    shifted = np.concatenate([np.zeros(160 * 2, dtype=np.uint8), pcms[0]])[:n * 2]
+    c = run_product_batch(ma, cfg, [shifted.tobytes()], 1, 2)[0]
+    assert np.array_equal(c[1:], a[0][:-1])
+
+
+def test_linearity_of_the_power_path_at_full_size():
+    """Scaling the PCM by 2 adds ln 4 to every log-mel value above the floor and to log-energy."""
+    kw = dict(CONFIGS["c2"], energyFlag=1)
+    n = 160000
+    x = np.frombuffer(_pcm(n, 1, 2, 900, 16000, tone=0).tobytes(), dtype=np.int16) // 4
+    cfg = ma.make_config(**kw)
+    a = run_product_batch(ma, cfg, [x.astype(np.int16).tobytes()], 1, 2)[0]
+    b = run_product_batch(ma, cfg, [(x * 2).astype(np.int16).tobytes()], 1, 2)[0]
+    assert np.all(a[:, :40] > 1.0)
+    assert np.max(np.abs(b - a - np.log(4.0))) < 2e-5
+
+
+def test_kernel_timing_api():
+    import torch
+    kw = CONFIGS["c2"]
+    pcm = _pcm(160000, 1, 2, 1, 16000)
+    ctx = ma.Context(ma.make_config(**kw), 0)
+    plan = ma.Plan(ctx, 1, 2, [0], [160000])
+    assert plan.last_kernel_ms() < 0
+    plan.enable_timing(True)
+    plan.extract(torch.from_numpy(pcm).cuda())
+    ms = plan.last_kernel_ms()
+    assert 0 < ms < 1000

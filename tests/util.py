@@ -30,11 +30,13 @@ def column_kinds(kw):
     return kinds
 
 
-def assert_static_close(got, ref, kw, f64=False):
+def assert_static_close(got, ref, kw, f64=False, delta=False):
     """Tolerances for the static block: log-mel / log-energy 1e-4 absolute; cepstra and C0 1e-5
-    relative to the largest cepstral magnitude of the matrix; ZCR exact; brightness / sub-band
+    relative to the largest cepstral magnitude of the matrix; ZCR exact (the same crossing count,
+    the quotient rounded to single precision); brightness / sub-band
     fractions 1e-5 absolute; debug FFT magnitudes 1e-5 relative to the largest magnitude.
-    In f64 mode everything must agree to 1e-9 (relative to magnitude)."""
+    In f64 mode everything must agree to 1e-9 (relative to magnitude).  delta=True: the block holds
+    regression deltas; they inherit the tolerances, except that a ZCR delta is 1e-6 absolute."""
     kinds = column_kinds(kw) * kw.get("vecNum", 1)
     assert got.shape == ref.shape
     n = len(kinds)
@@ -51,7 +53,7 @@ def assert_static_close(got, ref, kw, f64=False):
         return
     for kind, atol_of in (("mel", lambda x: 1e-4), ("energy", lambda x: 1e-4),
                           ("cep", lambda x: 1e-5 * max(x, 1.0)), ("c0", lambda x: 1e-5 * max(x, 1.0)),
-                          ("zc", lambda x: 0.0), ("bright", lambda x: 1e-5), ("sub", lambda x: 1e-5),
+                          ("zc", lambda x: 1e-6), ("bright", lambda x: 1e-5), ("sub", lambda x: 1e-5),
                           ("fft", lambda x: 1e-5 * max(x, 1.0))):
         m = kinds == kind
         if not m.any() or g.shape[0] == 0:
@@ -60,6 +62,9 @@ def assert_static_close(got, ref, kw, f64=False):
             mx = float(np.max(np.abs(r[:, (kinds == "cep") | (kinds == "c0")])))
         else:
             mx = float(np.max(np.abs(r[:, m])))
+        if kind == "zc" and not delta:  # exact: the same count / (wlen - 1), rounded once to single precision
+            assert np.array_equal(g[:, m], r[:, m].astype(np.float32).astype(np.float64))
+            continue
         err = float(np.max(np.abs(g[:, m] - r[:, m])))
         assert err <= atol_of(mx), "%s: max error %g > %g" % (kind, err, atol_of(mx))
 
