@@ -44,12 +44,13 @@ struct MFCCPlan {
     std::vector<UttDesc> utts;
     int64_t totalRows = 0;
     int numTiles = 0, numChunks = 0;
-    int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0;
+    int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0, teamElems = 0, numRegBlocks = 0;
     int tabElems = 0, winPad = 0, featElems = 0, fbkElems = 0, rowTail = 0;
     int blocksPerCu = 1, numCus = 256, pplog = 4;
     size_t ldsBytes = 0;
     UttDesc *dUtts = nullptr;
-    int32_t *dTileUtt = nullptr, *dChunkUtt = nullptr, *dLaneSeg = nullptr;
+    int32_t *dTileUtt = nullptr, *dChunkUtt = nullptr, *dLaneSeg = nullptr, *dRegUtt = nullptr;
+    TileDesc *dTiles = nullptr;
     void *dStageTw = nullptr;
     std::vector<double> stageTw;
     int maxSeg = 1, zPitch = 0;
@@ -195,7 +196,9 @@ static int choose_tile(MFCCPlan *p)
     if (const char *e = getenv("MFCC_PPLOG")) // tuning aid
         if (front_variant_exists(log2nc, atoi(e))) pplog = atoi(e);
     p->pplog = pplog;
-    const int groups = front_groups(log2nc, pplog), lanes = front_lanes(log2nc, pplog);
+    const int teams = front_teams(log2nc, pplog);
+    const int groups = front_groups(log2nc, pplog) / teams; // frames in flight per team
+    const int lanes = front_lanes(log2nc, pplog);
     // work area of one frame: nc complex points with one pad point per 16, or the nc (t1, ek-t1)
     // pairs followed by the 2 (P+1) segment sums, whichever is larger
     const int zPitch = (std::max(2 * (nc + nc / 16), 2 * nc + 2 * (c->cfg.bankNum + 1)) + 3) & ~3;
@@ -260,15 +263,17 @@ static int choose_tile(MFCCPlan *p)
     p->fbkElems = c->cfg.fbankFlag ? 0 : ((groups * P + 3) & ~3);
     const size_t tabElems = (((size_t)p->winPad + 2 * (size_t)nc + (size_t)std::max(nc, 2) + (size_t)nc +
                               4 * (size_t)lanes * p->maxSeg) + 3) & ~(size_t)3;
+    int teamEl = 0;
     auto geometry = [&](int ft, bool tabLds, int &rowPitch, int &rawOrZ) {
         const long ninst = (long)(ft - 1) * c->cfg.inc + c->cfg.wlen + 1;
         rowPitch = (int)((ninst + rowTail + 3) & ~3L);
         const size_t rawBytes = (size_t)ninst * bpi + 48;
         size_t n = std::max((size_t)groups * zPitch, (rawBytes + el - 1) / el);
         rawOrZ = (int)((n + 3) & ~(size_t)3);
-        const size_t feat = ((size_t)ft * c->vSize + 3) & ~(size_t)3;
-        const size_t elems = (tabLds ? tabElems : 0) + (size_t)V * rowPitch + rawOrZ + feat +
-                             p->fbkElems + 8;
+        // staging area: the tile's rows plus one 16-byte vector of slack for the alignment shift
+        const size_t feat = (((size_t)ft * c->vSize + 3) & ~(size_t)3) + 4;
+        teamEl = (int)((size_t)V * rowPitch + rawOrZ + feat + p->fbkElems + 8);
+        const size_t elems = (tabLds ? tabElems : 0) + (size_t)teams * teamEl;
         return elems * el;
     };
     // Prefer the occupancy the registers allow, then LDS tables, then longer tiles.
@@ -276,7 +281,7 @@ static int choose_tile(MFCCPlan *p)
     bool bestTab = false;
     for (int blocks = wavesCap; blocks >= 1 && !bestFt; --blocks)
         for (int tab = 1; tab >= 0 && !bestFt; --tab)
-            for (int m = 2; m >= 1 && !bestFt; --m) {
+            for (int m = (teams > 1 ? 4 : 2); m >= 1 && !bestFt; --m) {
                 int rp, rz;
                 // Measured on MI355X: three 54,208-byte workgroups are not co-resident on a CU
                 // while three 49,072-byte ones are, so budget in 4 KiB steps.
@@ -310,11 +315,12 @@ static int choose_tile(MFCCPlan *p)
     p->tabElems = bestTab ? (int)tabElems : 0;
     p->blocksPerCu = bestBlocks;
     p->ldsBytes = geometry(bestFt, bestTab, p->rowPitch, p->rawOrZElems);
-    p->featElems = (int)(((size_t)bestFt * c->vSize + 3) & ~(size_t)3);
+    p->teamElems = teamEl;
+    p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
     const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->ldsBytes);
     if (getenv("MFCC_DEBUG"))
-        fprintf(stderr, "mfcc plan: points/lane %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
-                1 << pplog, bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
+        fprintf(stderr, "mfcc plan: points/lane %d, teams %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
+                1 << pplog, teams, bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
     if (occ > 0 && occ < p->blocksPerCu) p->blocksPerCu = occ;
     if (const char *e = getenv("MFCC_BLOCKS_PER_CU")) // tuning aid: resident workgroups per CU
         if (atoi(e) > 0) p->blocksPerCu = atoi(e);
@@ -326,26 +332,46 @@ static int finish_plan(MFCCPlan *p)
     MFCCContext *c = p->ctx;
     int rc = choose_tile(p);
     if (rc) return rc;
-    std::vector<int32_t> tileUtt, chunkUtt;
-    int64_t tiles = 0, chunks = 0;
+    std::vector<int32_t> tileUtt, chunkUtt, regUtt;
+    std::vector<TileDesc> tileDesc;
+    int64_t tiles = 0, chunks = 0, regBlocks = 0;
+    const int64_t bpi = (int64_t)p->channels * p->bps;
+    if (p->framesPerTile > 4095) return set_error("internal: tile longer than 4095 frames"), MFCC_E_CONFIG;
     for (int u = 0; u < p->numUtts; ++u) {
         UttDesc &d = p->utts[u];
         const int nt = (d.numFrames + p->framesPerTile - 1) / p->framesPerTile;
         const int ncb = (d.ownCount + kStatRows - 1) / kStatRows;
+        const int nrb = (d.numFrames + kRegRows - 1) / kRegRows;
         if (tiles + nt > 0x7fffffffLL || chunks + ncb > 0x7fffffffLL)
             return set_error("batch too large: more than 2^31 tiles"), MFCC_E_ARG;
-        d.tileBegin = (int32_t)tiles;
+        d.regBegin = (int32_t)regBlocks;
         d.statBegin = (int32_t)chunks;
         tiles += nt;
         chunks += ncb;
+        regBlocks += nrb;
     }
     tileUtt.reserve((size_t)tiles);
+    tileDesc.reserve((size_t)tiles);
     chunkUtt.reserve((size_t)chunks);
+    regUtt.reserve((size_t)regBlocks);
     for (int u = 0; u < p->numUtts; ++u) {
         const UttDesc &d = p->utts[u];
-        tileUtt.insert(tileUtt.end(), (size_t)((d.numFrames + p->framesPerTile - 1) / p->framesPerTile), u);
+        for (int f0 = 0; f0 < d.numFrames; f0 += p->framesPerTile) {
+            const int nf = std::min(p->framesPerTile, d.numFrames - f0);
+            const int64_t first = (int64_t)f0 * c->cfg.inc + d.lead; // first instant of the first frame
+            const int64_t first0 = first > 0 ? first - 1 : 0;         // plus its pre-emphasis predecessor
+            const uint64_t off = (uint64_t)(d.byteOff + first0 * bpi);
+            if (off > kTileOffMask) return set_error("PCM buffer larger than 2^48 bytes"), MFCC_E_ARG;
+            TileDesc td;
+            td.src = off | ((uint64_t)nf << 48) | ((uint64_t)(first > 0 ? 1 : 0) << 60);
+            td.outRow = d.outRow + f0;
+            tileDesc.push_back(td);
+            tileUtt.push_back(u);
+        }
         chunkUtt.insert(chunkUtt.end(), (size_t)((d.ownCount + kStatRows - 1) / kStatRows), u);
+        regUtt.insert(regUtt.end(), (size_t)((d.numFrames + kRegRows - 1) / kRegRows), u);
     }
+    p->numRegBlocks = (int)regBlocks;
     p->numTiles = (int)tiles;
     p->numChunks = (int)chunks;
     HIP_TRY(hipSetDevice(c->device));
@@ -358,9 +384,19 @@ static int finish_plan(MFCCPlan *p)
     HIP_TRY(hipMalloc((void **)&p->dUtts, nu * sizeof(UttDesc)));
     if (!p->utts.empty())
         HIP_TRY(hipMemcpy(p->dUtts, p->utts.data(), p->utts.size() * sizeof(UttDesc), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void **)&p->dTileUtt, std::max<size_t>(tileUtt.size(), 1) * sizeof(int32_t)));
-    if (!tileUtt.empty())
-        HIP_TRY(hipMemcpy(p->dTileUtt, tileUtt.data(), tileUtt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&p->dTiles, std::max<size_t>(tileDesc.size(), 1) * sizeof(TileDesc)));
+    if (!tileDesc.empty())
+        HIP_TRY(hipMemcpy(p->dTiles, tileDesc.data(), tileDesc.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    if (c->cfg.zeroMeanSigFlag) {
+        HIP_TRY(hipMalloc((void **)&p->dTileUtt, std::max<size_t>(tileUtt.size(), 1) * sizeof(int32_t)));
+        if (!tileUtt.empty())
+            HIP_TRY(hipMemcpy(p->dTileUtt, tileUtt.data(), tileUtt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (c->cfg.regreOrder > 1) {
+        HIP_TRY(hipMalloc((void **)&p->dRegUtt, std::max<size_t>(regUtt.size(), 1) * sizeof(int32_t)));
+        if (!regUtt.empty())
+            HIP_TRY(hipMemcpy(p->dRegUtt, regUtt.data(), regUtt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     {
         const int rc2 = upload_tab(c->cfg.precision, p->stageTw, &p->dStageTw);
         if (rc2) return rc2;
@@ -500,6 +536,8 @@ extern "C" void MFCCPlanDestroy(MFCCPlan *p)
     if (p->ctx) (void)hipSetDevice(p->ctx->device);
     (void)hipFree(p->dUtts);
     (void)hipFree(p->dTileUtt);
+    (void)hipFree(p->dTiles);
+    (void)hipFree(p->dRegUtt);
     (void)hipFree(p->dChunkUtt);
     (void)hipFree(p->dLaneSeg);
     (void)hipFree(p->dStageTw);
@@ -557,8 +595,10 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     FrontArgs<T> a;
     memset(&a, 0, sizeof a);
     a.pcm = static_cast<const unsigned char *>(pcmDev);
+    a.tiles = p->dTiles;
     a.utts = p->dUtts;
     a.tileUtt = p->dTileUtt;
+    a.zeroMean = c->cfg.zeroMeanSigFlag ? 1 : 0;
     a.out = static_cast<T *>(outDev);
     a.numTiles = p->numTiles;
     a.wlen = c->cfg.wlen;
@@ -593,6 +633,7 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.rowPitch = p->rowPitch;
     a.rowTail = p->rowTail;
     a.rawOrZElems = p->rawOrZElems;
+    a.teamElems = p->teamElems;
     a.tabElems = p->tabElems;
     a.winPad = p->winPad;
     a.featElems = p->featElems;
@@ -621,7 +662,8 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     }
 #endif
     // persistent workgroups: as many as stay resident, each walks tiles with a grid stride
-    const int blocks = (int)std::min<int64_t>(p->numTiles, (int64_t)p->numCus * p->blocksPerCu);
+    const int teams = front_teams(c->tab.log2nc, p->pplog);
+    const int blocks = (int)std::min<int64_t>((p->numTiles + teams - 1) / teams, (int64_t)p->numCus * p->blocksPerCu);
     const int rc = launch_front(c->cfg.precision, c->tab.log2nc, p->pplog, &a, blocks, p->ldsBytes, stream);
     if (rc) return set_error("static-feature kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;
@@ -638,9 +680,8 @@ static int run_regress(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
         memset(&a, 0, sizeof a);
         a.data = static_cast<T *>(outDev);
         a.utts = p->dUtts;
-        a.tileUtt = p->dTileUtt;
-        a.numTiles = p->numTiles;
-        a.framesPerTile = p->framesPerTile;
+        a.blockUtt = p->dRegUtt;
+        a.numBlocks = p->numRegBlocks;
         a.vSize = c->vSize;
         a.step = c->step;
         a.srcCol = (order - 2) * c->vSize;
@@ -648,7 +689,7 @@ static int run_regress(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
         a.delwin = c->cfg.delwin;
         a.sigmaT2 = sigmaT2;
         a.invSigmaT2 = (T)(1.0 / sigmaT2);
-        const int rc = launch_regress(c->cfg.precision, &a, p->numTiles, stream);
+        const int rc = launch_regress(c->cfg.precision, &a, p->numRegBlocks, stream);
         if (rc) return set_error("regression kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     }
     return MFCC_OK;

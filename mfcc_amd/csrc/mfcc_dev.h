@@ -8,6 +8,7 @@ namespace mfcc {
 constexpr int kBlock = 256;       // threads per workgroup of every kernel (4 waves of 64)
 constexpr int kMaxLog2Nc = 13;    // fftN <= 16384
 constexpr int kStatRows = 1024;   // rows per workgroup of the z-norm statistics kernels
+constexpr int kRegRows = 64;      // rows per workgroup pass of the regression kernel
 
 // One utterance (or one rank's shard of a long recording) as the kernels see it.
 struct UttDesc {
@@ -17,7 +18,7 @@ struct UttDesc {
     int32_t numFrames;  // frames computed from the buffer (local frames 0 .. numFrames-1)
     int32_t lead;       // 1: instant 0 only serves as the pre-emphasis predecessor of instant 1
                         //    (the buffer starts inside a longer recording); 0: instant 0 starts the signal
-    int32_t tileBegin;  // index of this utterance's first tile in the tile table
+    int32_t regBegin;   // index of this utterance's first row block in the regression table
     int32_t ownBegin;   // first local frame that enters the z-norm statistics / is normalised
     int32_t ownCount;   // number of such frames
     int32_t statBegin;  // index of this utterance's first statistics chunk
@@ -25,12 +26,24 @@ struct UttDesc {
     double mean[4];     // value subtracted from the derived rows {L, R, mid, side} (0 = option off)
 };
 
+// One tile of the static-feature kernel: up to framesPerTile consecutive frames of one utterance,
+// resolved on the host so that a team needs a single 16-byte load to start on it.
+struct TileDesc {
+    uint64_t src;   // bits 0..47: byte offset (inside the PCM buffer) of the pre-emphasis predecessor
+                    // of the tile's first sample, or of that sample itself when it starts the signal;
+                    // bits 48..59: frames in the tile; bit 60: the predecessor exists
+    int64_t outRow; // output row of the tile's first frame
+};
+constexpr uint64_t kTileOffMask = (1ull << 48) - 1;
+
 // Arguments of the static-feature kernel.
 template <typename T>
 struct FrontArgs {
     const unsigned char *pcm;
-    const UttDesc *utts;
-    const int32_t *tileUtt;
+    const TileDesc *tiles;
+    const UttDesc *utts;      // read only for the row means (zeroMean != 0)
+    const int32_t *tileUtt;   // utterance of each tile (read only if zeroMean != 0)
+    int zeroMean;
     T *out;
     int numTiles;
     int wlen, inc, framesPerTile;
@@ -50,7 +63,8 @@ struct FrontArgs {
     const T *dct;          // P x M, k-major: cos(pi (j+1) (k + 0.5) / P)
     int rowPitch;          // elements per derived row in LDS
     int rowTail;           // elements zero-filled behind the last sample of a tile (>= fftN - wlen + 1)
-    int rawOrZElems;       // elements reserved for max(raw PCM bytes, all work areas)
+    int rawOrZElems;       // elements reserved for max(raw PCM bytes, a team's work areas)
+    int teamElems;         // elements of one team's LDS region (rows, work areas, staging, sums)
     int tabElems;          // elements of the LDS copy of the tables (0: tables are read through L1/L2)
     int winPad;            // elements reserved for the window inside that copy
     int featElems;         // elements of the static-feature staging area (framesPerTile x vSize, padded)
@@ -63,8 +77,8 @@ template <typename T>
 struct RegressArgs {
     T *data;
     const UttDesc *utts;
-    const int32_t *tileUtt;
-    int numTiles, framesPerTile;
+    const int32_t *blockUtt; // utterance of each kRegRows-row block
+    int numBlocks;
     int vSize, step, srcCol, dstCol, delwin;
     T invSigmaT2;
     double sigmaT2;
@@ -85,10 +99,11 @@ int launch_front(int precision, int log2nc, int pplog, const void *args, int num
                  size_t ldsBytes, void *stream);
 bool front_variant_exists(int log2nc, int pplog); // pplog: log2 of complex points per lane (4, 3, 2)
 int front_groups(int log2nc, int pplog);          // frames in flight per workgroup
+int front_teams(int log2nc, int pplog);           // independent teams (tile streams) per workgroup
 int front_lanes(int log2nc, int pplog);           // lanes that share one frame
 int front_waves_limit(int precision, int log2nc, int pplog); // waves per SIMD the kernel is compiled for
 int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, size_t ldsBytes);
-int launch_regress(int precision, const void *args, int numTiles, void *stream);
+int launch_regress(int precision, const void *args, int numBlocks, void *stream);
 int launch_colstats(int precision, const void *args, int numChunks, void *stream);
 int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream);
 int launch_shardfinal(const StatArgs<float> &a, int numChunks, double *sumsOut, void *stream);

@@ -28,7 +28,26 @@ struct Geo {
     static constexpr int PPL = NC / G;                            // complex points per lane
     static constexpr int RBMAX = PPLOG < 4 ? PPLOG : 4;           // log2 of the largest stage radix
     static constexpr int GROUPS = kBlock / G;                     // frames in flight per workgroup
+    // A team is the set of lanes that shares one tile (its sample rows, work areas and staging
+    // area).  Frames that fit a wave make every wave its own team: the waves of a workgroup then
+    // run independent tile streams with no workgroup barrier inside the tile loop.
+    static constexpr int TEAM = G <= 64 ? 64 : kBlock;
+    static constexpr int NTEAMS = kBlock / TEAM;
+    static constexpr int GT = TEAM / G;                           // frames in flight per team
 };
+
+// Barrier among the lanes of one team.
+template <int TEAM>
+__device__ __forceinline__ void team_sync()
+{
+    if constexpr (TEAM <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
 
 // Index of complex point i inside a work area: one pad point after every 16, so that the
 // transposing exchange between two FFT stages stays (nearly) free of LDS bank conflicts.
@@ -166,9 +185,9 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
 // reference's un-fused double code (needed whenever the sign of a sample is observable: ZCR).
 // ------------------------------------------------------------------------------------------
 
-template <typename T, bool EXACT, int CH>
+template <typename T, bool EXACT, int CH, int STRIDE>
 __device__ __forceinline__ void unpack_tile(T *rows, const unsigned *raw, int rowPitch, int V, int bps,
-                                            int mis, int lead, long long first, int ns,
+                                            int mis, int lead, int ns,
                                             const double *mean, double preK, int tid)
 {
     using A = typename std::conditional<EXACT, double, float>::type; // arithmetic type
@@ -178,9 +197,9 @@ __device__ __forceinline__ void unpack_tile(T *rows, const unsigned *raw, int ro
     A mu[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) mu[v] = (A)mean[v];
-    for (int q = tid; q < nq; q += kBlock) {
+    for (int q = tid; q < nq; q += STRIDE) {
         const int s0 = 4 * q;
-        const bool hasPrev = (first + s0) > 0;           // false only for the signal's first sample
+        const bool hasPrev = (lead + s0) > 0;            // false only for the signal's first sample
         const int rel = s0 + lead - 1;                    // raw instant of the predecessor of s0
         const int p0 = mis + (rel < 0 ? 0 : rel) * bpi;
         A x[5][4]; // [instant: predecessor, s0 .. s0+3][row]
@@ -246,7 +265,7 @@ __device__ __forceinline__ int window_sample(const unsigned (&d)[NW])
         return (int)v;
 }
 
-template <typename T, bool EXACT, int CH, int BPS>
+template <typename T, bool EXACT, int CH, int BPS, int STRIDE>
 __device__ __forceinline__ void unpack_tile_fast(T *rows, const unsigned *raw, int rowPitch, int V,
                                                  int ns, const double *mean, double preK, int tid)
 {
@@ -257,7 +276,7 @@ __device__ __forceinline__ void unpack_tile_fast(T *rows, const unsigned *raw, i
     A mu[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) mu[v] = (A)mean[v];
-    for (int q = tid; q < nq; q += kBlock) {
+    for (int q = tid; q < nq; q += STRIDE) {
         const int s0 = 4 * q;
         const unsigned *src = raw + q * BPI; // byte 4 q BPI: predecessor of sample s0
         unsigned d[NW];
@@ -303,18 +322,18 @@ __device__ __forceinline__ void unpack_tile_fast(T *rows, const unsigned *raw, i
     }
 }
 
-template <typename T, int CH, int BPS>
+template <typename T, int CH, int BPS, int STRIDE>
 __device__ __forceinline__ void unpack_tile_fast_sel(bool exact, T *rows, const unsigned *raw,
                                                      int rowPitch, int V, int ns, const double *mean,
                                                      double preK, int tid)
 {
     if constexpr (sizeof(T) == 8) {
-        unpack_tile_fast<T, true, CH, BPS>(rows, raw, rowPitch, V, ns, mean, preK, tid);
+        unpack_tile_fast<T, true, CH, BPS, STRIDE>(rows, raw, rowPitch, V, ns, mean, preK, tid);
     } else {
         if (exact)
-            unpack_tile_fast<T, true, CH, BPS>(rows, raw, rowPitch, V, ns, mean, preK, tid);
+            unpack_tile_fast<T, true, CH, BPS, STRIDE>(rows, raw, rowPitch, V, ns, mean, preK, tid);
         else
-            unpack_tile_fast<T, false, CH, BPS>(rows, raw, rowPitch, V, ns, mean, preK, tid);
+            unpack_tile_fast<T, false, CH, BPS, STRIDE>(rows, raw, rowPitch, V, ns, mean, preK, tid);
     }
 }
 
@@ -362,7 +381,7 @@ __device__ __forceinline__ void unpack_tile_fast_sel(bool exact, T *rows, const 
 constexpr int front_waves_rule(bool f64, int log2nc, int pplog)
 {
     if (pplog == 4) return f64 ? (log2nc <= 7 ? 2 : 1) : (log2nc <= 9 ? 3 : (log2nc <= 11 ? 2 : 1));
-    if (pplog == 3) return f64 ? 2 : 4;
+    if (pplog == 3) return f64 ? 2 : 3;
     return f64 ? 3 : 5;
 }
 template <typename T, int LOG2NC, int PPLOG>
@@ -380,21 +399,27 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     const FrontArgs<T> a)
 {
     using GEO = Geo<LOG2NC, PPLOG>;
-    constexpr int NC = GEO::NC, G = GEO::G, PPL = GEO::PPL, GROUPS = GEO::GROUPS;
+    constexpr int NC = GEO::NC, G = GEO::G, PPL = GEO::PPL;
+    constexpr int TEAM = GEO::TEAM, NTEAMS = GEO::NTEAMS, GT = GEO::GT;
     constexpr int R0B = LOG2NC < GEO::RBMAX ? LOG2NC : GEO::RBMAX, R0 = 1 << R0B; // first-stage radix
     constexpr int NPAIR = PPL / 2 > 0 ? PPL / 2 : 1;
+    constexpr int VEC = 16 / (int)sizeof(T); // elements of one 16-byte store
+
+    const int tid = threadIdx.x;
+    // wave-uniform when a team is a wave: keeps the tile bookkeeping in scalar registers
+    const int team = NTEAMS > 1 ? __builtin_amdgcn_readfirstlane(tid / TEAM) : 0;
+    const int tt = tid & (TEAM - 1);                // lane inside the team
+    const int l = tt & (G - 1), grp = tt / G;       // lane inside the frame, frame slot inside the team
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *ldsTab = reinterpret_cast<T *>(smem);        // table copies if TLDS (see below)
-    T *rows = ldsTab + a.tabElems;                  // V x rowPitch pre-emphasised samples
-    T *zbuf = rows + a.V * a.rowPitch;              // GROUPS work areas; raw PCM bytes alias it
-    T *feat = zbuf + a.rawOrZElems;                 // framesPerTile x vSize static features
-    T *fbkSep = feat + a.featElems;                 // GROUPS x P log-mel values (cepstral mode)
+    T *rows = ldsTab + a.tabElems + team * a.teamElems; // V x rowPitch pre-emphasised samples
+    T *zbuf = rows + a.V * a.rowPitch;              // GT work areas; raw PCM bytes alias it
+    T *featBase = zbuf + a.rawOrZElems;             // framesPerTile x vSize static features (+ VEC)
+    T *fbkSep = featBase + a.featElems;             // GT x P log-mel values (cepstral mode)
     T *red = fbkSep + a.fbkElems;                   // 8 elements for cross-wave sums
     unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
 
-    const int tid = threadIdx.x;
-    const int l = tid & (G - 1), grp = tid / G;
     const int bpi = a.channels * a.bps;
 
     // tables: [window (winPad) | twiddles (2 nc) | split factors (nc) | loWt (nc) | laneSeg (4 G maxSeg)]
@@ -418,73 +443,81 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 
     STAMP_DECL
     STAMP_START;
-    for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
-        const int u = a.tileUtt[tile];
-        const UttDesc ud = a.utts[u];
-        const int f0 = (tile - ud.tileBegin) * a.framesPerTile;
-        const int nf = min(a.framesPerTile, ud.numFrames - f0);
-        const long long first = (long long)f0 * a.inc + ud.lead; // first instant of the first frame
-        const long long first0 = first > 0 ? first - 1 : 0;      // plus its pre-emphasis predecessor
+    for (int tile = blockIdx.x * NTEAMS + team; tile < a.numTiles; tile += gridDim.x * NTEAMS) {
+        const TileDesc td = a.tiles[tile];
+        const int nf = (int)((td.src >> 48) & 0xfffu);
+        const int lead = (int)((td.src >> 60) & 1u);            // the first sample has a predecessor
+        const unsigned char *g0 = a.pcm + (td.src & kTileOffMask);
         const int ns = (nf - 1) * a.inc + a.wlen;                 // frame samples in the tile
-        const int lead = (int)(first - first0);
+        double mean[4] = {0, 0, 0, 0};
+        if (a.zeroMean) {
+            const double *m = a.utts[a.tileUtt[tile]].mean;
+            mean[0] = m[0], mean[1] = m[1], mean[2] = m[2], mean[3] = m[3];
+        }
+        // Staging area shifted so that it is 16-byte aligned exactly where the output is.
+        T *dst = a.out + td.outRow * a.step;
+        const int mis = a.step == a.vSize ? (int)((reinterpret_cast<unsigned long long>(dst) / sizeof(T)) & (VEC - 1)) : 0;
+        T *feat = featBase + mis;
 
         // A: tile bytes -> LDS -> derived, mean-free, pre-emphasised rows (see unpack_tile*).
         const bool exact = sizeof(T) == 8 || a.zcFlag != 0;
-        const bool fastA = first > 0 && (a.bps == 2 || a.bps == 3);
+        const bool fastA = lead && (a.bps == 2 || a.bps == 3);
         if (fastA) {
             // Copy starts exactly at the predecessor of the tile's first sample (16-byte vector
             // loads from a possibly unaligned address), the last partial vector byte by byte so
             // that nothing behind the tile's bytes is touched.
             typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
-            const unsigned char *g0 = a.pcm + ud.byteOff + first0 * bpi;
             const int nbytes = (ns + 1) * bpi, nfull = nbytes >> 4;
             if (!SKIP(7)) {
-                for (int i = tid; i < nfull; i += kBlock) {
-                    const u4u vv4 = reinterpret_cast<const u4u *>(g0)[i];
-                    reinterpret_cast<uint4 *>(raw)[i] = make_uint4(vv4.x, vv4.y, vv4.z, vv4.w);
+                for (int i = tt; i < nfull; i += 2 * TEAM) { // two loads in flight per lane
+                    const bool second = i + TEAM < nfull;
+                    const u4u va = reinterpret_cast<const u4u *>(g0)[i];
+                    u4u vb = va;
+                    if (second) vb = reinterpret_cast<const u4u *>(g0)[i + TEAM];
+                    reinterpret_cast<uint4 *>(raw)[i] = make_uint4(va.x, va.y, va.z, va.w);
+                    if (second) reinterpret_cast<uint4 *>(raw)[i + TEAM] = make_uint4(vb.x, vb.y, vb.z, vb.w);
                 }
-                for (int i = (nfull << 4) + tid; i < nbytes; i += kBlock)
+                for (int i = (nfull << 4) + tt; i < nbytes; i += TEAM)
                     reinterpret_cast<unsigned char *>(raw)[i] = g0[i];
             }
-            __syncthreads();
+            team_sync<TEAM>();
             STAMP(0);
             if (!SKIP(0)) {
                 if (a.channels == 2) {
                     if (a.bps == 2)
-                        unpack_tile_fast_sel<T, 2, 2>(exact, rows, raw, a.rowPitch, a.V, ns, ud.mean, a.preK, tid);
+                        unpack_tile_fast_sel<T, 2, 2, TEAM>(exact, rows, raw, a.rowPitch, a.V, ns, mean, a.preK, tt);
                     else
-                        unpack_tile_fast_sel<T, 2, 3>(exact, rows, raw, a.rowPitch, a.V, ns, ud.mean, a.preK, tid);
+                        unpack_tile_fast_sel<T, 2, 3, TEAM>(exact, rows, raw, a.rowPitch, a.V, ns, mean, a.preK, tt);
                 } else {
                     if (a.bps == 2)
-                        unpack_tile_fast_sel<T, 1, 2>(exact, rows, raw, a.rowPitch, a.V, ns, ud.mean, a.preK, tid);
+                        unpack_tile_fast_sel<T, 1, 2, TEAM>(exact, rows, raw, a.rowPitch, a.V, ns, mean, a.preK, tt);
                     else
-                        unpack_tile_fast_sel<T, 1, 3>(exact, rows, raw, a.rowPitch, a.V, ns, ud.mean, a.preK, tid);
+                        unpack_tile_fast_sel<T, 1, 3, TEAM>(exact, rows, raw, a.rowPitch, a.V, ns, mean, a.preK, tt);
                 }
             }
         } else {
             // General form (first tile of an utterance, 32-bit samples): 16-byte aligned vector
             // loads (each holds >= 1 valid byte, so it stays inside the buffer's pages), samples
             // picked at run-time byte offsets, double arithmetic.
-            const unsigned char *gbase = a.pcm + ud.byteOff + first0 * bpi;
-            const unsigned long long gaddr = (unsigned long long)gbase;
-            const int mis = (int)(gaddr & 15ull);
-            const uint4 *src = reinterpret_cast<const uint4 *>(gaddr - mis);
-            const int nvec = (mis + (ns + lead) * bpi + 15) >> 4;
-            for (int i = tid; i < nvec; i += kBlock) reinterpret_cast<uint4 *>(raw)[i] = src[i];
-            __syncthreads();
+            const unsigned long long gaddr = reinterpret_cast<unsigned long long>(g0);
+            const int gmis = (int)(gaddr & 15ull);
+            const uint4 *src = reinterpret_cast<const uint4 *>(gaddr - gmis);
+            const int nvec = (gmis + (ns + lead) * bpi + 15) >> 4;
+            for (int i = tt; i < nvec; i += TEAM) reinterpret_cast<uint4 *>(raw)[i] = src[i];
+            team_sync<TEAM>();
             STAMP(0);
             if (a.channels == 2)
-                unpack_tile<T, true, 2>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
+                unpack_tile<T, true, 2, TEAM>(rows, raw, a.rowPitch, a.V, a.bps, gmis, lead, ns, mean, a.preK, tt);
             else
-                unpack_tile<T, true, 1>(rows, raw, a.rowPitch, a.V, a.bps, mis, lead, first, ns, ud.mean, a.preK, tid);
+                unpack_tile<T, true, 1, TEAM>(rows, raw, a.rowPitch, a.V, a.bps, gmis, lead, ns, mean, a.preK, tt);
         }
-        for (int s = tid; s < a.rowTail; s += kBlock)
+        for (int s = tt; s < a.rowTail; s += TEAM)
             for (int v = 0; v < a.V; ++v) rows[v * a.rowPitch + ns + s] = (T)0;
-        __syncthreads();
+        team_sync<TEAM>();
         STAMP(1);
 
         const int nItems = nf * a.V;
-        for (int base = 0; base < nItems; base += GROUPS) {
+        for (int base = 0; base < nItems; base += GT) {
             const int item = base + grp;
             const bool active = item < nItems;
             const int it = active ? item : 0; // V is 1..4: no general division needed
@@ -535,7 +568,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 }
             }
             STAMP(2);
-            if (a.energyFlag) te = group_sum<T, G>(te, red, tid);
+            if (a.energyFlag) te = group_sum<T, G>(te, red, tt);
             if (a.zcFlag) { // sign changes between neighbours of the un-windowed frame (main.c:227)
 #pragma unroll
                 for (int i = 0; i < PPL; ++i) {
@@ -547,7 +580,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     zc += (c01 && w1 > 0) ? 1 : 0;
                     zc += (c12 && w2 > 0) ? 1 : 0;
                 }
-                zc = group_sum<int, G>(zc, reinterpret_cast<int *>(red), tid);
+                zc = group_sum<int, G>(zc, reinterpret_cast<int *>(red), tt);
             }
 
             // ---- nc-point complex FFT of z[n] = x[2n] + i x[2n+1]   (Realft mfcc.c:262-270)
@@ -594,8 +627,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     regTotal += pa[q] + pb[q];
                     regNum += (T)(k + 1) * pa[q] + (T)(k2 + 1) * pb[q];
                 }
-                regTotal = group_sum<T, G>(regTotal, red, tid);
-                regNum = group_sum<T, G>(regNum, red, tid);
+                regTotal = group_sum<T, G>(regTotal, red, tt);
+                regNum = group_sum<T, G>(regNum, red, tt);
             }
             STAMP(4);
             group_sync<G>(); // every lane has read its Z points: the work area can be reused
@@ -624,8 +657,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                             e += pv;
                             ek += (T)(k + 1) * pv;
                         }
-                        e = group_sum<T, G>(e, red, tid);
-                        ek = group_sum<T, G>(ek, red, tid);
+                        e = group_sum<T, G>(e, red, tt);
+                        ek = group_sum<T, G>(ek, red, tt);
                         if (active && l == 0) fo[subAt + g] = e;
                         total += e;
                         num += ek;
@@ -710,18 +743,24 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             group_sync<G>();
             STAMP(7);
         }
-        __syncthreads();
+        team_sync<TEAM>();
         STAMP(8);
 
         // ---- tile rows -> HBM (static block of every row; delta slots are written later)
-        const long long row0 = ud.outRow + f0;
         if (a.step == a.vSize) { // no delta slots: the tile's rows are one contiguous run
-            T *dst = a.out + row0 * a.step;
-            for (int i = tid; i < (SKIP(8) ? 0 : nf * a.vSize); i += kBlock) dst[i] = feat[i];
+            const int n = SKIP(8) ? 0 : nf * a.vSize;
+            const int head = mis ? min(n, VEC - mis) : 0; // elements before the first 16-byte boundary
+            const int nv = (n - head) / VEC;
+            if (tt < head) dst[tt] = feat[tt];
+            typedef T vecT __attribute__((ext_vector_type(VEC)));
+            const vecT *fv = reinterpret_cast<const vecT *>(feat + head);
+            vecT *dv = reinterpret_cast<vecT *>(dst + head);
+            for (int i = tt; i < nv; i += TEAM) dv[i] = fv[i];
+            for (int i = head + nv * VEC + tt; i < n; i += TEAM) dst[i] = feat[i];
         } else {
-            for (int r = tid >> 6; r < (SKIP(8) ? 0 : nf); r += kBlock / 64) {
-                T *dst = a.out + (row0 + r) * a.step;
-                for (int c = tid & 63; c < a.vSize; c += 64) dst[c] = feat[r * a.vSize + c];
+            for (int r = tt >> 6; r < (SKIP(8) ? 0 : nf); r += TEAM / 64) {
+                T *drow = dst + (long long)r * a.step;
+                for (int c = tt & 63; c < a.vSize; c += 64) drow[c] = feat[r * a.vSize + c];
             }
         }
         STAMP(9);
@@ -736,11 +775,11 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_regress(const RegressArgs<T> a)
 {
-    for (int tile = blockIdx.x; tile < a.numTiles; tile += gridDim.x) {
-        const int u = a.tileUtt[tile];
+    for (int blk = blockIdx.x; blk < a.numBlocks; blk += gridDim.x) {
+        const int u = a.blockUtt[blk];
         const UttDesc ud = a.utts[u];
-        const int f0 = (tile - ud.tileBegin) * a.framesPerTile;
-        const int nf = min(a.framesPerTile, ud.numFrames - f0);
+        const int f0 = (blk - ud.regBegin) * kRegRows;
+        const int nf = min(kRegRows, ud.numFrames - f0);
         const int n = ud.numFrames;
         T *base = a.data + ud.outRow * a.step;
         for (int i = threadIdx.x; i < nf * a.vSize; i += kBlock) {
@@ -1058,15 +1097,18 @@ int front_lanes(int log2nc, int pplog)
 
 int front_groups(int log2nc, int pplog) { return kBlock / front_lanes(log2nc, pplog); }
 
+int front_teams(int log2nc, int pplog) { return front_lanes(log2nc, pplog) <= 64 ? kBlock / 64 : 1; }
+
 int front_waves_limit(int precision, int log2nc, int pplog)
 {
     return front_waves_rule(precision == 1, log2nc, pplog);
 }
 
-int launch_regress(int precision, const void *args, int numTiles, void *stream)
+int launch_regress(int precision, const void *args, int numBlocks, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (numTiles <= 0) return 0;
+    if (numBlocks <= 0) return 0;
+    const int numTiles = numBlocks;
     if (precision == 1)
         hipLaunchKernelGGL(k_regress<double>, dim3(numTiles), dim3(kBlock), 0, st,
                            *static_cast<const RegressArgs<double> *>(args));
