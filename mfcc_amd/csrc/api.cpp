@@ -47,6 +47,7 @@ struct MFCCPlan {
     int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0, teamElems = 0, numRegBlocks = 0;
     int tabElems = 0, winPad = 0, featElems = 0, fbkElems = 0, rowTail = 0;
     int blocksPerCu = 1, numCus = 256, pplog = 4;
+    bool lean = false;
     size_t ldsBytes = 0;
     UttDesc *dUtts = nullptr;
     int32_t *dTileUtt = nullptr, *dChunkUtt = nullptr, *dLaneSeg = nullptr, *dRegUtt = nullptr;
@@ -317,10 +318,14 @@ static int choose_tile(MFCCPlan *p)
     p->ldsBytes = geometry(bestFt, bestTab, p->rowPitch, p->rawOrZElems);
     p->teamElems = teamEl;
     p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
-    const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->ldsBytes);
+    // Lean instantiation: mono 16-bit input, one row, even frame shift, none of the per-frame extras.
+    p->lean = prec == MFCC_PREC_F32 && pplog == 3 && bestTab && p->channels == 1 && p->bps == 2 && V == 1 &&
+              c->cfg.inc % 2 == 0 && !c->cfg.zeroCrossingFlag && !c->cfg.brightFlag && !c->cfg.subBandEFlag &&
+              !c->cfg.fftLength && !c->cfg.zeroMeanSigFlag && !getenv("MFCC_NO_LEAN");
+    const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->lean, p->ldsBytes);
     if (getenv("MFCC_DEBUG"))
-        fprintf(stderr, "mfcc plan: points/lane %d, teams %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
-                1 << pplog, teams, bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
+        fprintf(stderr, "mfcc plan: points/lane %d, teams %d, lean %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
+                1 << pplog, teams, (int)p->lean, bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
     if (occ > 0 && occ < p->blocksPerCu) p->blocksPerCu = occ;
     if (const char *e = getenv("MFCC_BLOCKS_PER_CU")) // tuning aid: resident workgroups per CU
         if (atoi(e) > 0) p->blocksPerCu = atoi(e);
@@ -599,6 +604,7 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.utts = p->dUtts;
     a.tileUtt = p->dTileUtt;
     a.zeroMean = c->cfg.zeroMeanSigFlag ? 1 : 0;
+    a.lean = p->lean ? 1 : 0;
     a.out = static_cast<T *>(outDev);
     a.numTiles = p->numTiles;
     a.wlen = c->cfg.wlen;

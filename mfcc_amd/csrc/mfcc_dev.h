@@ -44,6 +44,7 @@ struct FrontArgs {
     const UttDesc *utts;      // read only for the row means (zeroMean != 0)
     const int32_t *tileUtt;   // utterance of each tile (read only if zeroMean != 0)
     int zeroMean;
+    int lean;                 // 1: the lean instantiation's promises hold (see k_front)
     T *out;
     int numTiles;
     int wlen, inc, framesPerTile;
@@ -102,7 +103,7 @@ int front_groups(int log2nc, int pplog);          // frames in flight per workgr
 int front_teams(int log2nc, int pplog);           // independent teams (tile streams) per workgroup
 int front_lanes(int log2nc, int pplog);           // lanes that share one frame
 int front_waves_limit(int precision, int log2nc, int pplog); // waves per SIMD the kernel is compiled for
-int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, size_t ldsBytes);
+int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, bool lean, size_t ldsBytes);
 int launch_regress(int precision, const void *args, int numBlocks, void *stream);
 int launch_colstats(int precision, const void *args, int numChunks, void *stream);
 int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream);

@@ -394,7 +394,7 @@ constexpr int front_waves_per_simd()
 // Fused static-feature kernel.  TLDS: window / twiddle / split tables are staged in LDS.
 // ------------------------------------------------------------------------------------------
 
-template <typename T, int LOG2NC, int PPLOG, bool TLDS>
+template <typename T, int LOG2NC, int PPLOG, bool TLDS, bool LEAN>
 __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>())) void k_front(
     const FrontArgs<T> a)
 {
@@ -405,6 +405,14 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     constexpr int NPAIR = PPL / 2 > 0 ? PPL / 2 : 1;
     constexpr int VEC = 16 / (int)sizeof(T); // elements of one 16-byte store
 
+    // LEAN: the host promises mono 16-bit input, one derived row, even frame shift and none of
+    // the zero-crossing / brightness / sub-band / magnitude / zero-mean options, so those paths
+    // (and the registers they pin) are compiled out.
+    const int F_zc = LEAN ? 0 : a.zcFlag, F_S = LEAN ? 0 : a.S, F_fftLength = LEAN ? 0 : a.fftLength;
+    const int F_bright = LEAN ? 0 : a.brightFlag, F_zeroMean = LEAN ? 0 : a.zeroMean;
+    const int F_channels = LEAN ? 1 : a.channels, F_bps = LEAN ? 2 : a.bps, F_V = LEAN ? 1 : a.V;
+    const int F_pairAligned = LEAN ? 1 : a.pairAligned;
+
     const int tid = threadIdx.x;
     // wave-uniform when a team is a wave: keeps the tile bookkeeping in scalar registers
     const int team = NTEAMS > 1 ? __builtin_amdgcn_readfirstlane(tid / TEAM) : 0;
@@ -414,13 +422,13 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *ldsTab = reinterpret_cast<T *>(smem);        // table copies if TLDS (see below)
     T *rows = ldsTab + a.tabElems + team * a.teamElems; // V x rowPitch pre-emphasised samples
-    T *zbuf = rows + a.V * a.rowPitch;              // GT work areas; raw PCM bytes alias it
+    T *zbuf = rows + F_V * a.rowPitch;              // GT work areas; raw PCM bytes alias it
     T *featBase = zbuf + a.rawOrZElems;             // framesPerTile x vSize static features (+ VEC)
     T *fbkSep = featBase + a.featElems;             // GT x P log-mel values (cepstral mode)
     T *red = fbkSep + a.fbkElems;                   // 8 elements for cross-wave sums
     unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
 
-    const int bpi = a.channels * a.bps;
+    const int bpi = F_channels * F_bps;
 
     // tables: [window (winPad) | twiddles (2 nc) | split factors (nc) | loWt (nc) | laneSeg (4 G maxSeg)]
     const T *win = a.window, *tw = a.tw, *split = a.splitTw, *lw = a.loWt;
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         const unsigned char *g0 = a.pcm + (td.src & kTileOffMask);
         const int ns = (nf - 1) * a.inc + a.wlen;                 // frame samples in the tile
         double mean[4] = {0, 0, 0, 0};
-        if (a.zeroMean) {
+        if (F_zeroMean) {
             const double *m = a.utts[a.tileUtt[tile]].mean;
             mean[0] = m[0], mean[1] = m[1], mean[2] = m[2], mean[3] = m[3];
         }
@@ -460,8 +468,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         T *feat = featBase + mis;
 
         // A: tile bytes -> LDS -> derived, mean-free, pre-emphasised rows (see unpack_tile*).
-        const bool exact = sizeof(T) == 8 || a.zcFlag != 0;
-        const bool fastA = lead && (a.bps == 2 || a.bps == 3);
+        const bool exact = sizeof(T) == 8 || F_zc != 0;
+        const bool fastA = lead && (F_bps == 2 || F_bps == 3);
         if (fastA) {
             // Copy starts exactly at the predecessor of the tile's first sample (16-byte vector
             // loads from a possibly unaligned address), the last partial vector byte by byte so
@@ -483,16 +491,16 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             team_sync<TEAM>();
             STAMP(0);
             if (!SKIP(0)) {
-                if (a.channels == 2) {
-                    if (a.bps == 2)
-                        unpack_tile_fast_sel<T, 2, 2, TEAM>(exact, rows, raw, a.rowPitch, a.V, ns, mean, a.preK, tt);
+                if (F_channels == 2) {
+                    if (F_bps == 2)
+                        unpack_tile_fast_sel<T, 2, 2, TEAM>(exact, rows, raw, a.rowPitch, F_V, ns, mean, a.preK, tt);
                     else
-                        unpack_tile_fast_sel<T, 2, 3, TEAM>(exact, rows, raw, a.rowPitch, a.V, ns, mean, a.preK, tt);
+                        unpack_tile_fast_sel<T, 2, 3, TEAM>(exact, rows, raw, a.rowPitch, F_V, ns, mean, a.preK, tt);
                 } else {
-                    if (a.bps == 2)
-                        unpack_tile_fast_sel<T, 1, 2, TEAM>(exact, rows, raw, a.rowPitch, a.V, ns, mean, a.preK, tt);
+                    if (F_bps == 2)
+                        unpack_tile_fast_sel<T, 1, 2, TEAM>(exact, rows, raw, a.rowPitch, F_V, ns, mean, a.preK, tt);
                     else
-                        unpack_tile_fast_sel<T, 1, 3, TEAM>(exact, rows, raw, a.rowPitch, a.V, ns, mean, a.preK, tt);
+                        unpack_tile_fast_sel<T, 1, 3, TEAM>(exact, rows, raw, a.rowPitch, F_V, ns, mean, a.preK, tt);
                 }
             }
         } else {
@@ -506,23 +514,23 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             for (int i = tt; i < nvec; i += TEAM) reinterpret_cast<uint4 *>(raw)[i] = src[i];
             team_sync<TEAM>();
             STAMP(0);
-            if (a.channels == 2)
-                unpack_tile<T, true, 2, TEAM>(rows, raw, a.rowPitch, a.V, a.bps, gmis, lead, ns, mean, a.preK, tt);
+            if (F_channels == 2)
+                unpack_tile<T, true, 2, TEAM>(rows, raw, a.rowPitch, F_V, F_bps, gmis, lead, ns, mean, a.preK, tt);
             else
-                unpack_tile<T, true, 1, TEAM>(rows, raw, a.rowPitch, a.V, a.bps, gmis, lead, ns, mean, a.preK, tt);
+                unpack_tile<T, true, 1, TEAM>(rows, raw, a.rowPitch, F_V, F_bps, gmis, lead, ns, mean, a.preK, tt);
         }
         for (int s = tt; s < a.rowTail; s += TEAM)
-            for (int v = 0; v < a.V; ++v) rows[v * a.rowPitch + ns + s] = (T)0;
+            for (int v = 0; v < F_V; ++v) rows[v * a.rowPitch + ns + s] = (T)0;
         team_sync<TEAM>();
         STAMP(1);
 
-        const int nItems = nf * a.V;
+        const int nItems = nf * F_V;
         for (int base = 0; base < nItems; base += GT) {
             const int item = base + grp;
             const bool active = item < nItems;
             const int it = active ? item : 0; // V is 1..4: no general division needed
-            const int fr = a.V == 1 ? it : (a.V == 2 ? it >> 1 : (a.V == 4 ? it >> 2 : it / 3));
-            const int vv = it - fr * a.V;
+            const int fr = F_V == 1 ? it : (F_V == 2 ? it >> 1 : (F_V == 4 ? it >> 2 : it / 3));
+            const int vv = it - fr * F_V;
             const T *x = rows + vv * a.rowPitch + fr * a.inc;
             T *Zt = zbuf + grp * a.zPitch;
             cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
@@ -551,7 +559,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     const int n = l + G * b + r * (NC / R0);
                     const int s0 = 2 * n;
                     T x0, x1;
-                    if (a.pairAligned) { // frame starts on an even sample: one 2-element LDS read
+                    if (F_pairAligned) { // frame starts on an even sample: one 2-element LDS read
                         const cpx<T> xv = *reinterpret_cast<const cpx<T> *>(x + s0);
                         x0 = xv.x;
                         x1 = xv.y;
@@ -569,7 +577,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             }
             STAMP(2);
             if (a.energyFlag) te = group_sum<T, G>(te, red, tt);
-            if (a.zcFlag) { // sign changes between neighbours of the un-windowed frame (main.c:227)
+            if (F_zc) { // sign changes between neighbours of the un-windowed frame (main.c:227)
 #pragma unroll
                 for (int i = 0; i < PPL; ++i) {
                     const int s0 = 2 * (l + G * i);
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             }
             // Brightness without sub-bands: power-weighted mean bin index straight from registers.
             T regTotal = 0, regNum = 0;
-            if (a.brightFlag && a.S == 0) {
+            if (F_bright && F_S == 0) {
 #pragma unroll
                 for (int q = 0; q < NPAIR; ++q) {
                     const int k = l + G * q;
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 
             // ---- sub-band energies / brightness / debug magnitudes need the plain power values
             //      of the whole frame: park them in the work area first (call sites main.c:235-236)
-            if (a.S > 0 || a.fftLength > 0) {
+            if (F_S > 0 || F_fftLength > 0) {
 #pragma unroll
                 for (int q = 0; q < NPAIR; ++q) {
                     const int k = l + G * q;
@@ -644,10 +652,10 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     if (NC > 1) Pw[k2] = pb[q];
                 }
                 group_sync<G>();
-                if (a.S > 0) {
-                    const int nseg = a.S;
+                if (F_S > 0) {
+                    const int nseg = F_S;
                     const int width = NC / nseg;
-                    const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
+                    const int subAt = a.M + a.c0Flag + a.energyFlag + F_zc + F_bright;
                     T total = 0, num = 0;
                     for (int g = 0; g < nseg; ++g) {
                         const int lo = g * width, hi = (g == nseg - 1) ? NC : lo + width;
@@ -664,22 +672,22 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                         num += ek;
                     }
                     if (active && l == 0) {
-                        if (a.brightFlag)
-                            fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / total / (T)NC;
-                        for (int g = 0; g < a.S; ++g) fo[subAt + g] = fo[subAt + g] / total;
+                        if (F_bright)
+                            fo[a.M + a.c0Flag + a.energyFlag + F_zc] = num / total / (T)NC;
+                        for (int g = 0; g < F_S; ++g) fo[subAt + g] = fo[subAt + g] / total;
                     }
                 }
-                if (active && a.fftLength > 0) {                                   // main.c:247
-                    const int at = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag + a.S;
-                    for (int q = l; q < a.fftLength; q += G) fo[at + q] = tsqrt<T>(Pw[q]);
+                if (active && F_fftLength > 0) {                                   // main.c:247
+                    const int at = a.M + a.c0Flag + a.energyFlag + F_zc + F_bright + F_S;
+                    for (int q = l; q < F_fftLength; q += G) fo[at + q] = tsqrt<T>(Pw[q]);
                 }
                 group_sync<G>();
             }
-            if (a.S == 0 && a.brightFlag && active && l == 0)
-                fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = regNum / regTotal / (T)NC;
+            if (F_S == 0 && F_bright && active && l == 0)
+                fo[a.M + a.c0Flag + a.energyFlag + F_zc] = regNum / regTotal / (T)NC;
             if (active && l == 0) {
                 if (a.energyFlag) fo[a.M + a.c0Flag] = tlog<T>(te);                // main.c:243
-                if (a.zcFlag)
+                if (F_zc)
                     fo[a.M + a.c0Flag + a.energyFlag] = (T)zc / (T)(a.wlen - 1);   // main.c:244
             }
 
@@ -1008,49 +1016,63 @@ __global__ void k_uttmeans(UttDesc *utts, int numUtts, const unsigned long long 
         if (e_ != hipSuccess) return (int)e_; \
     } while (0)
 
-template <typename T, int L, int PL, bool TLDS>
+template <typename T, int L, int PL, bool TLDS, bool LEAN>
 static int launch_front_t(const FrontArgs<T> &a, int numBlocks, size_t lds, hipStream_t st)
 {
     static bool attrSet[16] = {};
     int dev = 0;
     MFCC_HIP_OK(hipGetDevice(&dev));
     if (dev < 16 && !attrSet[dev]) {
-        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS>),
+        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS, LEAN>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attrSet[dev] = true;
     }
-    hipLaunchKernelGGL((k_front<T, L, PL, TLDS>), dim3(numBlocks), dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((k_front<T, L, PL, TLDS, LEAN>), dim3(numBlocks), dim3(kBlock), lds, st, a);
     return (int)hipGetLastError();
 }
 
-template <typename T, int L, int PL, bool TLDS>
+template <typename T, int L, int PL, bool TLDS, bool LEAN>
 static int front_occ_t(size_t lds)
 {
     int n = 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS, LEAN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_front<T, L, PL, TLDS>, kBlock, lds) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_front<T, L, PL, TLDS, LEAN>, kBlock, lds) != hipSuccess)
         return 0;
     return n;
 }
 
-// Dispatch over (precision, log2 nc, points per lane, tables in LDS).  op 0: launch, op 1: occupancy.
-template <typename T, int L, int PL>
-static int front_do(int op, bool tl, const void *args, int numBlocks, size_t lds, hipStream_t st)
+// The lean instantiation exists for single precision, 8 points per lane, tables in LDS.
+template <typename T, int PL>
+constexpr bool front_has_lean()
 {
-    if (op == 1) return tl ? front_occ_t<T, L, PL, true>(lds) : front_occ_t<T, L, PL, false>(lds);
+    return sizeof(T) == 4 && PL == 3;
+}
+
+// Dispatch over (precision, log2 nc, points per lane, tables in LDS, lean).  op 0: launch,
+// op 1: occupancy.
+template <typename T, int L, int PL>
+static int front_do(int op, bool tl, bool lean, const void *args, int numBlocks, size_t lds, hipStream_t st)
+{
+    if constexpr (front_has_lean<T, PL>()) {
+        if (lean && tl) {
+            if (op == 1) return front_occ_t<T, L, PL, true, true>(lds);
+            return launch_front_t<T, L, PL, true, true>(*static_cast<const FrontArgs<T> *>(args), numBlocks, lds, st);
+        }
+    }
+    if (op == 1) return tl ? front_occ_t<T, L, PL, true, false>(lds) : front_occ_t<T, L, PL, false, false>(lds);
     const FrontArgs<T> &a = *static_cast<const FrontArgs<T> *>(args);
-    return tl ? launch_front_t<T, L, PL, true>(a, numBlocks, lds, st)
-              : launch_front_t<T, L, PL, false>(a, numBlocks, lds, st);
+    return tl ? launch_front_t<T, L, PL, true, false>(a, numBlocks, lds, st)
+              : launch_front_t<T, L, PL, false, false>(a, numBlocks, lds, st);
 }
 
 template <typename T>
-static int front_dispatch(int op, int log2nc, int pplog, bool tl, const void *args, int numBlocks,
+static int front_dispatch(int op, int log2nc, int pplog, bool tl, bool lean, const void *args, int numBlocks,
                           size_t lds, hipStream_t st)
 {
     switch (log2nc * 8 + pplog) {
 #define MFCC_CASE(L, PL) \
-    case L * 8 + PL: return front_do<T, L, PL>(op, tl, args, numBlocks, lds, st);
+    case L * 8 + PL: return front_do<T, L, PL>(op, tl, lean, args, numBlocks, lds, st);
         MFCC_CASE(1, 4) MFCC_CASE(2, 4) MFCC_CASE(3, 4) MFCC_CASE(4, 4) MFCC_CASE(5, 4)
         MFCC_CASE(6, 4) MFCC_CASE(7, 4) MFCC_CASE(8, 4) MFCC_CASE(9, 4) MFCC_CASE(10, 4)
         MFCC_CASE(11, 4) MFCC_CASE(12, 4) MFCC_CASE(13, 4)
@@ -1076,15 +1098,16 @@ int launch_front(int precision, int log2nc, int pplog, const void *args, int num
     if (numBlocks <= 0) return 0;
     const bool tl = precision == 1 ? static_cast<const FrontArgs<double> *>(args)->tabElems > 0
                                    : static_cast<const FrontArgs<float> *>(args)->tabElems > 0;
-    return precision == 1 ? front_dispatch<double>(0, log2nc, pplog, tl, args, numBlocks, ldsBytes, st)
-                          : front_dispatch<float>(0, log2nc, pplog, tl, args, numBlocks, ldsBytes, st);
+    const bool lean = precision == 1 ? false : static_cast<const FrontArgs<float> *>(args)->lean != 0;
+    return precision == 1 ? front_dispatch<double>(0, log2nc, pplog, tl, false, args, numBlocks, ldsBytes, st)
+                          : front_dispatch<float>(0, log2nc, pplog, tl, lean, args, numBlocks, ldsBytes, st);
 }
 
 // Workgroups of the static-feature kernel that the runtime says fit one CU (0 = unknown).
-int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, size_t ldsBytes)
+int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, bool lean, size_t ldsBytes)
 {
-    const int n = precision == 1 ? front_dispatch<double>(1, log2nc, pplog, tabLds, nullptr, 0, ldsBytes, nullptr)
-                                 : front_dispatch<float>(1, log2nc, pplog, tabLds, nullptr, 0, ldsBytes, nullptr);
+    const int n = precision == 1 ? front_dispatch<double>(1, log2nc, pplog, tabLds, false, nullptr, 0, ldsBytes, nullptr)
+                                 : front_dispatch<float>(1, log2nc, pplog, tabLds, lean, nullptr, 0, ldsBytes, nullptr);
     return n < 0 ? 0 : n;
 }
 
