@@ -449,6 +449,29 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         __syncthreads();
     }
 
+    // Lean mode: a lane windows the same sample positions and weights the same bins in every
+    // frame, so those table entries live in registers for the whole launch.
+    T wreg[LEAN ? 2 * PPL : 1], lwreg[LEAN ? 2 * NPAIR : 1];
+    cpx<T> swreg[LEAN ? NPAIR : 1];
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int b = 0; b < PPL / R0; ++b)
+#pragma unroll
+            for (int r = 0; r < R0; ++r) {
+                const int s0 = 2 * (l + G * b + r * (NC / R0));
+                wreg[2 * (b * R0 + r)] = win[s0];
+                wreg[2 * (b * R0 + r) + 1] = win[s0 + 1];
+            }
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            const int k = l + G * q;
+            const int k2 = k == 0 ? NC / 2 : NC - k;
+            lwreg[2 * q] = lw[k];
+            lwreg[2 * q + 1] = lw[NC > 1 ? k2 : 0];
+            swreg[q] = reinterpret_cast<const cpx<T> *>(split)[k];
+        }
+    }
+
     STAMP_DECL
     STAMP_START;
     for (int tile = blockIdx.x * NTEAMS + team; tile < a.numTiles; tile += gridDim.x * NTEAMS) {
@@ -567,8 +590,15 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                         x0 = x[s0];
                         x1 = x[s0 + 1];
                     }
-                    const cpx<T> wv = *reinterpret_cast<const cpx<T> *>(win + s0);
-                    const T w0 = wv.x, w1 = wv.y;
+                    T w0, w1;
+                    if constexpr (LEAN) {
+                        w0 = wreg[2 * (b * R0 + r)];
+                        w1 = wreg[2 * (b * R0 + r) + 1];
+                    } else {
+                        const cpx<T> wv = *reinterpret_cast<const cpx<T> *>(win + s0);
+                        w0 = wv.x;
+                        w1 = wv.y;
+                    }
                     x0 *= w0;
                     x1 *= w1;
                     te += x0 * x0 + x1 * x1;
@@ -609,7 +639,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             for (int q = 0; q < NPAIR; ++q) {
                 const int k = l + G * q; // k == 0 (lane 0, q == 0) reads a don't-care word: fixed up below
                 const cpx<T> za = Z[zpad(k)], zb = Z[zpad(NC - k)];
-                const cpx<T> sw = reinterpret_cast<const cpx<T> *>(split)[k];
+                const cpx<T> sw = LEAN ? swreg[q] : reinterpret_cast<const cpx<T> *>(split)[k];
                 const T c = sw.x, s = sw.y;
                 const T ex = (T)0.5 * (za.x + zb.x), ey = (T)0.5 * (za.y - zb.y);
                 const T ox = (T)0.5 * (za.y + zb.y), oy = (T)-0.5 * (za.x - zb.x);
@@ -699,7 +729,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             for (int q = 0; q < NPAIR; ++q) {
                 const int k = l + G * q;
                 const int k2 = k == 0 ? NC / 2 : NC - k;
-                const T t1 = lw[k] * pa[q], t2 = lw[k2] * pb[q];
+                const T t1 = (LEAN ? lwreg[2 * q] : lw[k]) * pa[q];
+                const T t2 = (LEAN ? lwreg[2 * q + 1] : lw[k2]) * pb[q];
                 AB[k] = {t1, pa[q] - t1};
                 if (NC > 1) AB[k2] = {t2, pb[q] - t2};
             }
