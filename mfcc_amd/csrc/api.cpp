@@ -225,7 +225,8 @@ static int choose_tile(MFCCPlan *p)
     }
     {
         // Mel segments: segment s (0..P) = the bins whose lower channel is s (contiguous, because
-        // loChan never decreases over the pass band).  Longest first, each to the least loaded lane.
+        // loChan never decreases over the pass band); a segment without bins still gets a slot, so
+        // that its sums are written as zeros.
         const int P1 = c->cfg.bankNum + 1;
         std::vector<int> sb(P1, 0), se(P1, 0);
         for (int k = 0; k < nc; ++k) {
@@ -234,23 +235,60 @@ static int choose_tile(MFCCPlan *p)
             if (se[ch] == 0) sb[ch] = k;
             se[ch] = k + 1;
         }
-        p->maxSeg = (P1 + lanes - 1) / lanes;
-        std::vector<int> order(P1), load(lanes, 0), count(lanes, 0);
+        // Every round each lane sums one segment, 4 bins per step; the lanes of a frame read
+        // 8-byte entries from 32 LDS banks, so segments of one round whose first bins share a bank
+        // collide on every step.  Longest first, each segment goes to the round where it adds the
+        // fewest LDS cycles (steps x worst bank multiplicity), one spare round allowed.
+        const int minRounds = (P1 + lanes - 1) / lanes;
+        const int rounds = minRounds + 1;
+        std::vector<int> order(P1);
         for (int i = 0; i < P1; ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(),
                          [&](int x, int y) { return se[x] - sb[x] > se[y] - sb[y]; });
+        std::vector<std::vector<int>> inRound(rounds);
+        auto roundCost = [&](const std::vector<int> &segs) {
+            int cost = 0;
+            for (int step = 0;; ++step) {
+                int mult[32] = {0}, worst = 0;
+                for (int sg : segs) {
+                    const int len = se[sg] - sb[sg];
+                    if (len > 4 * step) worst = std::max(worst, ++mult[(sb[sg] + 4 * step) & 31]);
+                }
+                if (!worst) break;
+                cost += 4 * worst;
+            }
+            return cost + 6; // fixed price of a round: its table read, its two stores
+        };
+        for (int sg : order) {
+            int best = -1, bestDelta = 0;
+            for (int r = 0; r < rounds; ++r) {
+                if ((int)inRound[r].size() >= lanes) continue;
+                const int before = inRound[r].empty() ? 0 : roundCost(inRound[r]);
+                inRound[r].push_back(sg);
+                const int delta = roundCost(inRound[r]) - before;
+                inRound[r].pop_back();
+                if (best < 0 || delta < bestDelta) best = r, bestDelta = delta;
+            }
+            inRound[best].push_back(sg);
+        }
+        int used = 0;
+        for (int r = 0; r < rounds; ++r)
+            if (!inRound[r].empty()) used = r + 1;
+        p->maxSeg = std::max(used, 1);
         p->laneSeg.assign((size_t)lanes * p->maxSeg * 4, 0);
         for (size_t i = 0; i < (size_t)lanes * p->maxSeg; ++i) p->laneSeg[4 * i + 2] = -1;
-        for (int s : order) {
-            int best = -1;
-            for (int ln = 0; ln < lanes; ++ln)
-                if (count[ln] < p->maxSeg && (best < 0 || load[ln] < load[best])) best = ln;
-            int32_t *e = &p->laneSeg[((size_t)best * p->maxSeg + count[best]) * 4];
-            e[0] = sb[s];
-            e[1] = se[s];
-            e[2] = s;
-            load[best] += std::max(se[s] - sb[s], 1);
-            ++count[best];
+        for (int r = 0; r < p->maxSeg; ++r)
+            for (size_t ln = 0; ln < inRound[r].size(); ++ln) {
+                const int sg = inRound[r][ln];
+                int32_t *e = &p->laneSeg[(ln * p->maxSeg + r) * 4];
+                e[0] = sb[sg];
+                e[1] = se[sg];
+                e[2] = sg;
+            }
+        if (getenv("MFCC_DEBUG")) {
+            int total = 0;
+            for (int r = 0; r < p->maxSeg; ++r) total += roundCost(inRound[r]);
+            fprintf(stderr, "mfcc plan: mel rounds %d, modelled LDS cycles per frame pair %d\n", p->maxSeg, total);
         }
     }
     const size_t el = prec == MFCC_PREC_F64 ? 8 : 4;

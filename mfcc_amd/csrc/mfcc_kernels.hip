@@ -128,6 +128,53 @@ __device__ __forceinline__ float tsqrt<float>(float x) { return sqrtf(x); }
 template <>
 __device__ __forceinline__ double tsqrt<double>(double x) { return sqrt(x); }
 
+// Single-precision complex points from LDS as individual ds_read_b64 instructions.  Left to the
+// compiler, neighbouring 8-byte reads are fused into ds_read2_b64, which moves 128 B/clk where two
+// ds_read_b64 move 256 B/clk.  N points at a constant byte stride are issued back to back and
+// drained by one wait, which also ties the results to that wait for the compiler's scheduler.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char *)p;
+}
+
+template <int OFF>
+__device__ __forceinline__ v2f lds_rd64(unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "LDS offset field is 16 bits");
+    v2f r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+    return r;
+}
+
+__device__ __forceinline__ void lds_drain(v2f &a, v2f &b, v2f &c, v2f &d)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+// out[i] = *(base + i * STRIDE bytes), i < N (N a multiple of 4, STRIDE >= 0)
+template <int N, int STRIDE, int I = 0>
+__device__ __forceinline__ void lds_issue(v2f (&t)[N], unsigned addr)
+{
+    if constexpr (I < N) {
+        t[I] = lds_rd64<I * STRIDE>(addr);
+        lds_issue<N, STRIDE, I + 1>(t, addr);
+    }
+}
+
+template <int N, int STRIDE>
+__device__ __forceinline__ void lds_read_strided(cpx<float> *out, const void *base)
+{
+    static_assert(N % 4 == 0, "points are drained four at a time");
+    v2f t[N];
+    lds_issue<N, STRIDE>(t, lds_addr(base));
+#pragma unroll
+    for (int i = 0; i < N; i += 4) lds_drain(t[i], t[i + 1], t[i + 2], t[i + 3]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = {t[i].x, t[i].y};
+}
+
 // ------------------------------------------------------------------------------------------
 // Stockham stages through the LDS work area Z (nc complex), radix <= 16 in registers.
 // Stage with sub-transform size NS: butterfly j reads points j + r*nc/R, multiplies point r by
@@ -152,8 +199,13 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int j = l + G * b;
+            // zpad(j + r STRIDE) = zpad(j) + r (STRIDE + STRIDE / 16): STRIDE is a multiple of 16
+            if constexpr (sizeof(T) == 4 && R % 4 == 0 && STRIDE % 16 == 0) {
+                lds_read_strided<R, (STRIDE + STRIDE / 16) * 8>(&v[b * R], &Z[zpad(j)]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[b * R + r] = Z[zpad(j + r * STRIDE)];
+                for (int r = 0; r < R; ++r) v[b * R + r] = Z[zpad(j + r * STRIDE)];
+            }
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -745,7 +797,13 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 const int4 sg = lseg[l * a.maxSeg + sidx];
                 cpx<T> acc = {0, 0};
                 for (int k = sg.x; k < sg.y; k += 4) { // 4 loads in flight; reads past the segment
-                    const cpx<T> v0 = AB[k], v1 = AB[k + 1], v2 = AB[k + 2], v3 = AB[k + 3];
+                    cpx<T> vq[4];
+                    if constexpr (sizeof(T) == 4) {
+                        lds_read_strided<4, 8>(vq, &AB[k]);
+                    } else {
+                        vq[0] = AB[k], vq[1] = AB[k + 1], vq[2] = AB[k + 2], vq[3] = AB[k + 3];
+                    }
+                    const cpx<T> v0 = vq[0], v1 = vq[1], v2 = vq[2], v3 = vq[3];
                     acc = cadd(acc, v0);                // stay inside the work area and are dropped
                     if (k + 1 < sg.y) acc = cadd(acc, v1);
                     if (k + 2 < sg.y) acc = cadd(acc, v2);
