@@ -152,8 +152,17 @@ __device__ __forceinline__ void lds_drain(v2f &a, v2f &b, v2f &c, v2f &d)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+__device__ __forceinline__ void lds_drain(v2f &a, v2f &b, v2f &c)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void lds_drain(v2f &a, v2f &b)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lds_drain(v2f &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
 
-// out[i] = *(base + i * STRIDE bytes), i < N (N a multiple of 4, STRIDE >= 0)
+// out[i] = *(base + i * STRIDE bytes), i < N (STRIDE >= 0)
 template <int N, int STRIDE, int I = 0>
 __device__ __forceinline__ void lds_issue(v2f (&t)[N], unsigned addr)
 {
@@ -166,11 +175,13 @@ __device__ __forceinline__ void lds_issue(v2f (&t)[N], unsigned addr)
 template <int N, int STRIDE>
 __device__ __forceinline__ void lds_read_strided(cpx<float> *out, const void *base)
 {
-    static_assert(N % 4 == 0, "points are drained four at a time");
     v2f t[N];
     lds_issue<N, STRIDE>(t, lds_addr(base));
 #pragma unroll
-    for (int i = 0; i < N; i += 4) lds_drain(t[i], t[i + 1], t[i + 2], t[i + 3]);
+    for (int i = 0; i + 4 <= N; i += 4) lds_drain(t[i], t[i + 1], t[i + 2], t[i + 3]);
+    if constexpr (N % 4 == 3) lds_drain(t[N - 3], t[N - 2], t[N - 1]);
+    if constexpr (N % 4 == 2) lds_drain(t[N - 2], t[N - 1]);
+    if constexpr (N % 4 == 1) lds_drain(t[N - 1]);
 #pragma unroll
     for (int i = 0; i < N; ++i) out[i] = {t[i].x, t[i].y};
 }
@@ -187,7 +198,7 @@ using LanePoints = cpx<T>[Geo<LOG2NC, PPLOG>::PPL]; // the complex points one la
 // Twiddles are stored per stage, [r-1][j mod NS] = exp(-2 pi i r (j mod NS) / (NS R)), so that the
 // lanes of a wave read consecutive (or identical) 8-byte words: no LDS bank conflicts.  TWOFF is
 // the complex offset of this stage's block in that table (the blocks follow each other).
-template <typename T, int LOG2NC, int PPLOG, int LOGNS, int TWOFF>
+template <typename T, int LOG2NC, int PPLOG, int LOGNS, int TWOFF, bool TWLDS>
 __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<T> *Z, int l,
                                            const cpx<T> *tw)
 {
@@ -200,7 +211,7 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
         for (int b = 0; b < NB; ++b) {
             const int j = l + G * b;
             // zpad(j + r STRIDE) = zpad(j) + r (STRIDE + STRIDE / 16): STRIDE is a multiple of 16
-            if constexpr (sizeof(T) == 4 && R % 4 == 0 && STRIDE % 16 == 0) {
+            if constexpr (sizeof(T) == 4 && STRIDE % 16 == 0) {
                 lds_read_strided<R, (STRIDE + STRIDE / 16) * 8>(&v[b * R], &Z[zpad(j)]);
             } else {
 #pragma unroll
@@ -210,8 +221,15 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const int m = (l + G * b) & (NS - 1);
+            cpx<T> w[R > 1 ? R - 1 : 1];
+            if constexpr (sizeof(T) == 4 && TWLDS && R > 1) {
+                lds_read_strided<R - 1, NS * 8>(w, &tw[TWOFF + m]);
+            } else {
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[b * R + r] = cmul(v[b * R + r], tw[TWOFF + (r - 1) * NS + m]);
+                for (int r = 1; r < R; ++r) w[r - 1] = tw[TWOFF + (r - 1) * NS + m];
+            }
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[b * R + r] = cmul(v[b * R + r], w[r - 1]);
         }
         group_sync<G>(); // every read of Z is done before any lane overwrites it
     }
@@ -226,7 +244,7 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
     }
     group_sync<G>();
     if constexpr (LOGNS + RB < LOG2NC)
-        fft_stages<T, LOG2NC, PPLOG, LOGNS + RB, TWOFF + (LOGNS > 0 ? (R - 1) * NS : 0)>(v, Z, l, tw);
+        fft_stages<T, LOG2NC, PPLOG, LOGNS + RB, TWOFF + (LOGNS > 0 ? (R - 1) * NS : 0), TWLDS>(v, Z, l, tw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -629,30 +647,43 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             } else
 #pragma unroll
             for (int b = 0; b < PPL / R0; ++b) {
+                // sample pairs (2n, 2n+1) and their window values for n = l + G b + r nc/R0
+                cpx<T> xs[R0], ws[R0];
+                const int n0 = l + G * b;
+                if constexpr (sizeof(T) == 4) {
+                    if (F_pairAligned) { // frame starts on an even sample: 8-byte aligned pairs
+                        lds_read_strided<R0, 8 * (NC / R0)>(xs, x + 2 * n0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R0; ++r) {
+                            const int s0 = 2 * (n0 + r * (NC / R0));
+                            xs[r] = {x[s0], x[s0 + 1]};
+                        }
+                    }
+                    if constexpr (LEAN) {
+#pragma unroll
+                        for (int r = 0; r < R0; ++r) ws[r] = {wreg[2 * (b * R0 + r)], wreg[2 * (b * R0 + r) + 1]};
+                    } else if constexpr (TLDS) {
+                        lds_read_strided<R0, 8 * (NC / R0)>(ws, win + 2 * n0);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R0; ++r)
+                            ws[r] = *reinterpret_cast<const cpx<T> *>(win + 2 * (n0 + r * (NC / R0)));
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R0; ++r) {
+                        const int s0 = 2 * (n0 + r * (NC / R0));
+                        if (F_pairAligned)
+                            xs[r] = *reinterpret_cast<const cpx<T> *>(x + s0);
+                        else
+                            xs[r] = {x[s0], x[s0 + 1]};
+                        ws[r] = *reinterpret_cast<const cpx<T> *>(win + s0);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < R0; ++r) {
-                    const int n = l + G * b + r * (NC / R0);
-                    const int s0 = 2 * n;
-                    T x0, x1;
-                    if (F_pairAligned) { // frame starts on an even sample: one 2-element LDS read
-                        const cpx<T> xv = *reinterpret_cast<const cpx<T> *>(x + s0);
-                        x0 = xv.x;
-                        x1 = xv.y;
-                    } else {
-                        x0 = x[s0];
-                        x1 = x[s0 + 1];
-                    }
-                    T w0, w1;
-                    if constexpr (LEAN) {
-                        w0 = wreg[2 * (b * R0 + r)];
-                        w1 = wreg[2 * (b * R0 + r) + 1];
-                    } else {
-                        const cpx<T> wv = *reinterpret_cast<const cpx<T> *>(win + s0);
-                        w0 = wv.x;
-                        w1 = wv.y;
-                    }
-                    x0 *= w0;
-                    x1 *= w1;
+                    const T x0 = xs[r].x * ws[r].x, x1 = xs[r].y * ws[r].y;
                     te += x0 * x0 + x1 * x1;
                     v[b * R0 + r] = {x0, x1};
                 }
@@ -674,12 +705,29 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             }
 
             // ---- nc-point complex FFT of z[n] = x[2n] + i x[2n+1]   (Realft mfcc.c:262-270)
-            if (!SKIP(2)) fft_stages<T, LOG2NC, PPLOG, 0, 0>(v, Z, l, reinterpret_cast<const cpx<T> *>(tw));
+            if (!SKIP(2)) fft_stages<T, LOG2NC, PPLOG, 0, 0, TLDS>(v, Z, l, reinterpret_cast<const cpx<T> *>(tw));
             STAMP(3);
 
             // ---- real-FFT split and power  (mfcc.c:274-290, ek of mfcc.c:153-155)
             // X[k] = E + w O, X[nc-k] = conj(E - w O), w = exp(-i pi k / nc); only |X|^2 is kept.
             T pa[NPAIR], pb[NPAIR];
+            cpx<T> zas[NPAIR], zbs[NPAIR]; // Z[k] and Z[nc - k] for k = l + G q
+            if constexpr (sizeof(T) == 4 && G % 16 == 0 && PPL >= 2) {
+                // zpad(l + G q) = zpad(l) + q (G + G/16), zpad(nc - l - G q) = zpad(nc - l) - q (G + G/16)
+                constexpr int QS = (G + G / 16) * 8;
+                cpx<T> rev[NPAIR];
+                lds_read_strided<NPAIR, QS>(zas, &Z[zpad(l)]);
+                lds_read_strided<NPAIR, QS>(rev, &Z[zpad(NC - l - G * (NPAIR - 1))]);
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) zbs[q] = rev[NPAIR - 1 - q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) {
+                    const int k = l + G * q;
+                    zas[q] = Z[zpad(k)];
+                    zbs[q] = Z[zpad(NC - k)];
+                }
+            }
             if (SKIP(3)) {
 #pragma unroll
                 for (int q = 0; q < NPAIR; ++q) {
@@ -690,7 +738,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 #pragma unroll
             for (int q = 0; q < NPAIR; ++q) {
                 const int k = l + G * q; // k == 0 (lane 0, q == 0) reads a don't-care word: fixed up below
-                const cpx<T> za = Z[zpad(k)], zb = Z[zpad(NC - k)];
+                const cpx<T> za = zas[q], zb = zbs[q];
                 const cpx<T> sw = LEAN ? swreg[q] : reinterpret_cast<const cpx<T> *>(split)[k];
                 const T c = sw.x, s = sw.y;
                 const T ex = (T)0.5 * (za.x + zb.x), ey = (T)0.5 * (za.y - zb.y);
