@@ -23,6 +23,20 @@ __device__ __forceinline__ cpx<T> cmul(cpx<T> a, cpx<T> b)
 {
     return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
+// Single precision: two packed instructions.  t = (a.x b.x, a.y b.x), then
+// (-a.y b.y + t.x, a.x b.y + t.y) with the operand halves picked by op_sel / op_sel_hi.
+template <>
+__device__ __forceinline__ cpx<float> cmul<float>(cpx<float> a, cpx<float> b)
+{
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    const v2 av = {a.x, a.y}, bv = {b.x, b.y};
+    v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "v"(bv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r)
+        : "v"(av), "v"(bv), "v"(t));
+    return {r.x, r.y};
+}
 // multiply by -i
 template <typename T>
 __device__ __forceinline__ cpx<T> cmul_mi(cpx<T> a) { return {a.y, -a.x}; }

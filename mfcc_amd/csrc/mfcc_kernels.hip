@@ -682,11 +682,13 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < R0; ++r) {
-                    const T x0 = xs[r].x * ws[r].x, x1 = xs[r].y * ws[r].y;
-                    te += x0 * x0 + x1 * x1;
-                    v[b * R0 + r] = {x0, x1};
-                }
+                for (int r = 0; r < R0; ++r) v[b * R0 + r] = {xs[r].x * ws[r].x, xs[r].y * ws[r].y};
+            }
+            if (a.energyFlag) { // te of mfcc.c:138-142 (the padding adds nothing)
+                cpx<T> e2 = {0, 0};
+#pragma unroll
+                for (int i = 0; i < PPL; ++i) e2 = {e2.x + v[i].x * v[i].x, e2.y + v[i].y * v[i].y};
+                te = e2.x + e2.y;
             }
             STAMP(2);
             if (a.energyFlag) te = group_sum<T, G>(te, red, tt);
