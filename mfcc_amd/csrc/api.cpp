@@ -35,6 +35,7 @@ struct MFCCContext {
     int device = 0;
     int M = 0, c0 = 0, D = 0, vSize = 0, step = 0;
     void *dWindow = nullptr, *dTw = nullptr, *dSplitTw = nullptr, *dLoWt = nullptr, *dDct = nullptr;
+    int dctPitch = 0, dctElems = 0;
 };
 
 struct MFCCPlan {
@@ -116,7 +117,20 @@ extern "C" int MFCCContextCreate(const MFCCConfig *cfgIn, int device, MFCCContex
     if ((rc = upload_tab(p, c->tab.tw, &c->dTw))) return rc;
     if ((rc = upload_tab(p, c->tab.splitTw, &c->dSplitTw))) return rc;
     if ((rc = upload_tab(p, c->tab.loWt, &c->dLoWt))) return rc;
-    if ((rc = upload_tab(p, c->tab.dct, &c->dDct))) return rc;
+    {
+        // j-major copy of the DCT table plus a row of ones (C0 = scaled plain sum, mfcc.c:197-208);
+        // rows zero-filled to an odd pitch >= P + 3: lanes read different rows at the same k (an
+        // odd pitch spreads them over the LDS banks) and up to 3 elements past P
+        const int P = cfg.bankNum, M = c->M, JW = M + c->c0;
+        c->dctPitch = (P + 3) | 1;
+        c->dctElems = cfg.fbankFlag ? 0 : JW * c->dctPitch;
+        std::vector<double> tr((size_t)std::max(c->dctElems, 1), 0.0);
+        if (!cfg.fbankFlag)
+            for (int j = 0; j < JW; ++j)
+                for (int k = 0; k < P; ++k)
+                    tr[(size_t)j * c->dctPitch + k] = j < M ? c->tab.dct[(size_t)k * M + j] : 1.0;
+        if ((rc = upload_tab(p, tr, &c->dDct))) return rc;
+    }
     *out = c.release();
     return MFCC_OK;
 }
@@ -299,10 +313,9 @@ static int choose_tile(MFCCPlan *p)
     p->rowTail = rowTail;
     const int wavesCap = front_waves_limit(prec, log2nc, pplog); // workgroups per CU the registers allow
     p->winPad = (c->tab.fftN + 2 + 3) & ~3; // window values, then zeros up to fftN + 2
-    p->fbkElems = c->cfg.fbankFlag ? 0 : ((groups * P + 3) & ~3);
     const size_t tabElems = (((size_t)p->winPad + 2 * (size_t)nc + (size_t)std::max(nc, 2) + (size_t)nc +
-                              4 * (size_t)lanes * p->maxSeg) + 3) & ~(size_t)3;
-    int teamEl = 0;
+                              4 * (size_t)lanes * p->maxSeg * 4 / el + (size_t)c->dctElems) + 3) & ~(size_t)3;
+    int teamEl = 0, fbkEl = 0;
     auto geometry = [&](int ft, bool tabLds, int &rowPitch, int &rawOrZ) {
         const long ninst = (long)(ft - 1) * c->cfg.inc + c->cfg.wlen + 1;
         rowPitch = (int)((ninst + rowTail + 3) & ~3L);
@@ -311,7 +324,8 @@ static int choose_tile(MFCCPlan *p)
         rawOrZ = (int)((n + 3) & ~(size_t)3);
         // staging area: the tile's rows plus one 16-byte vector of slack for the alignment shift
         const size_t feat = (((size_t)ft * c->vSize + 3) & ~(size_t)3) + 4;
-        teamEl = (int)((size_t)V * rowPitch + rawOrZ + feat + p->fbkElems + 8);
+        fbkEl = c->cfg.fbankFlag ? 0 : (int)(((size_t)ft * V * P + 3) & ~(size_t)3);
+        teamEl = (int)((size_t)V * rowPitch + rawOrZ + feat + fbkEl + 8);
         const size_t elems = (tabLds ? tabElems : 0) + (size_t)teams * teamEl;
         return elems * el;
     };
@@ -355,6 +369,7 @@ static int choose_tile(MFCCPlan *p)
     p->blocksPerCu = bestBlocks;
     p->ldsBytes = geometry(bestFt, bestTab, p->rowPitch, p->rawOrZElems);
     p->teamElems = teamEl;
+    p->fbkElems = fbkEl;
     p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
     // Lean instantiation: mono 16-bit input, one row, even frame shift, none of the per-frame extras.
     p->lean = prec == MFCC_PREC_F32 && pplog == 3 && bestTab && p->channels == 1 && p->bps == 2 && V == 1 &&
@@ -673,7 +688,9 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.maxSeg = p->maxSeg;
     a.pairAligned = (c->cfg.inc % 2 == 0) ? 1 : 0;
     a.zPitch = p->zPitch;
-    a.dct = static_cast<const T *>(c->dDct);
+    a.dctT = static_cast<const T *>(c->dDct);
+    a.dctPitch = c->dctPitch;
+    a.dctElems = c->dctElems;
     a.rowPitch = p->rowPitch;
     a.rowTail = p->rowTail;
     a.rawOrZElems = p->rawOrZElems;

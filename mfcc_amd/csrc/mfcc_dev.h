@@ -61,7 +61,9 @@ struct FrontArgs {
     int maxSeg;               // mel segments (bins sharing one lower channel) a lane sums at most
     int pairAligned;          // 1: every frame starts on an even sample of its row (inc is even)
     int zPitch;               // elements per frame work area
-    const T *dct;          // P x M, k-major: cos(pi (j+1) (k + 0.5) / P)
+    const T *dctT;         // (M + c0) x dctPitch, j-major: cos(pi (j+1) (k + 0.5) / P), then a row of ones
+                           // for C0; rows are zero from k = P to the (odd, >= P + 3) pitch
+    int dctPitch, dctElems; // dctElems = (M + c0) * dctPitch (0 in filterbank mode)
     int rowPitch;          // elements per derived row in LDS
     int rowTail;           // elements zero-filled behind the last sample of a tile (>= fftN - wlen + 1)
     int rawOrZElems;       // elements reserved for max(raw PCM bytes, a team's work areas)
@@ -69,7 +71,7 @@ struct FrontArgs {
     int tabElems;          // elements of the LDS copy of the tables (0: tables are read through L1/L2)
     int winPad;            // elements reserved for the window inside that copy
     int featElems;         // elements of the static-feature staging area (framesPerTile x vSize, padded)
-    int fbkElems;          // elements of the log-mel area, GROUPS x P (0 in filterbank mode)
+    int fbkElems;          // elements of the log-mel area, framesPerTile x V x P (0 in filterbank mode)
     unsigned long long *stamps; // diagnostic builds only: 12 per-phase cycle sums (else NULL)
     int skip;                   // diagnostic builds only: bit mask of phases to leave out
 };

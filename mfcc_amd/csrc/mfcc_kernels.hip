@@ -76,6 +76,19 @@ __device__ __forceinline__ V group_sum(V v, V *scratch, int tid)
 {
     if constexpr (G == 1) {
         return v;
+    } else if constexpr (G <= 64 && sizeof(V) == 4) {
+        // inside a row of 16 lanes through DPP (no LDS traffic), across rows by lane exchange
+        auto dpp_add = [](V x, auto ctrl) {
+            const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false);
+            return x + __builtin_bit_cast(V, y);
+        };
+        v = dpp_add(v, std::integral_constant<int, 0xB1>{});                        // quad_perm [1,0,3,2]
+        if constexpr (G >= 4) v = dpp_add(v, std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]
+        if constexpr (G >= 8) v = dpp_add(v, std::integral_constant<int, 0x141>{}); // row_half_mirror
+        if constexpr (G >= 16) v = dpp_add(v, std::integral_constant<int, 0x140>{}); // row_mirror
+        if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+        if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+        return v;
     } else if constexpr (G <= 64) {
 #pragma unroll
         for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -111,6 +124,19 @@ __device__ __forceinline__ double sub_mul_exact(double x, double xp, double k)
 #pragma clang fp contract(off)
     const double t = xp * k;
     return x - t;
+}
+
+// 16 x 16 x 4 matrix-core product-accumulate: lane (i, g) = (lane % 16, lane / 16) supplies
+// A[i][g] and B[g][i]; element r of the result is D[4 g + r][i] (float) or D[4 r + g][i] (double).
+template <typename T>
+using Acc4 = T __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Acc4<float> mfma16(float a, float b, Acc4<float> c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ Acc4<double> mfma16(double a, double b, Acc4<double> c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
 template <typename T>
@@ -494,15 +520,16 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     T *rows = ldsTab + a.tabElems + team * a.teamElems; // V x rowPitch pre-emphasised samples
     T *zbuf = rows + F_V * a.rowPitch;              // GT work areas; raw PCM bytes alias it
     T *featBase = zbuf + a.rawOrZElems;             // framesPerTile x vSize static features (+ VEC)
-    T *fbkSep = featBase + a.featElems;             // GT x P log-mel values (cepstral mode)
+    T *fbkSep = featBase + a.featElems;             // framesPerTile x V x P log-mel values (cepstral mode)
     T *red = fbkSep + a.fbkElems;                   // 8 elements for cross-wave sums
     unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
 
     const int bpi = F_channels * F_bps;
 
-    // tables: [window (winPad) | twiddles (2 nc) | split factors (nc) | loWt (nc) | laneSeg (4 G maxSeg)]
+    // tables: [window (winPad) | twiddles (2 nc) | split factors (nc) | loWt (nc) | laneSeg (4 G maxSeg) | dctT]
     const T *win = a.window, *tw = a.tw, *split = a.splitTw, *lw = a.loWt;
     const int4 *lseg = reinterpret_cast<const int4 *>(a.laneSeg);
+    const T *dctT = a.dctT;
     if constexpr (TLDS) {
         T *w = ldsTab, *t = w + a.winPad, *sp = t + 2 * NC, *lo = sp + (NC > 1 ? NC : 2);
         int *c = reinterpret_cast<int *>(lo + NC);
@@ -511,6 +538,9 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         for (int i = tid; i < (NC > 1 ? NC : 2); i += kBlock) sp[i] = a.splitTw[i];
         for (int i = tid; i < NC; i += kBlock) lo[i] = a.loWt[i];
         for (int i = tid; i < 4 * G * a.maxSeg; i += kBlock) c[i] = a.laneSeg[i];
+        T *dl = reinterpret_cast<T *>(c + 4 * G * a.maxSeg);
+        for (int i = tid; i < a.dctElems; i += kBlock) dl[i] = a.dctT[i];
+        dctT = dl;
         win = w;
         tw = t;
         split = sp;
@@ -630,7 +660,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             cpx<T> *AB = Z;                               // per bin (loWt*p, p - loWt*p)
             T *Tt = Zt + 2 * NC, *Ut = Tt + a.P + 1;      // per-segment sums of the two
             T *Pw = Zt;                                   // plain power values, before AB
-            T *fbk = fbkSep + grp * a.P;                  // log-mel values (only if fbkElems)
+            T *fbk = fbkSep + item * a.P;                 // log-mel values of the item (only if fbkElems)
             T *fo = feat + item * a.D;
 
             // ---- window, frame energy, zero crossings, first FFT stage input (Ham main.c:229,
@@ -868,29 +898,48 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             for (int ch = l; ch < (SKIP(6) ? 0 : a.P); ch += G) {
                 const T m = Ut[ch] + Tt[ch + 1];
                 const T lv = tlog<T>(m < (T)1 ? (T)1 : m);
-                if (a.fbkElems) fbk[ch] = lv;
+                if (active && a.fbkElems) fbk[ch] = lv;
                 if (active && a.fbankFlag) fo[ch] = lv;
             }
             group_sync<G>();
 
             STAMP(6);
-            // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208)
-            if (active && !a.fbankFlag) {
-                for (int j = l; j < a.M + a.c0Flag; j += G) {
-                    T acc = 0;
-                    if (j < a.M) {
-                        for (int k = 0; k < a.P; ++k) acc += fbk[k] * a.dct[k * a.M + j];
-                    } else {
-                        for (int k = 0; k < a.P; ++k) acc += fbk[k];
-                    }
-                    fo[j] = acc * a.mfnorm;
-                }
-            }
             // the next round overwrites the work area: every lane of the frame is done with it
             group_sync<G>();
             STAMP(7);
         }
         team_sync<TEAM>();
+        // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208) of the whole
+        //      tile: one lane per (frame, coefficient), summed over the channels in order
+        if (!a.fbankFlag) {
+            // out[item][j] = sum_k fbk[item][k] dct[j][k] as 16 x 16 x 4 matrix-core products: per
+            // step lane (i, g) = (lane % 16, lane / 16) feeds fbk[item i][k0 + g] and
+            // dct[coefficient i][k0 + g] and holds 4 items' results for coefficient i.
+            // The table's row M is all ones (C0); its rows are zero from k = P to the pitch.
+            const int JW = a.M + a.c0Flag;
+            const int wv = tt >> 6, i16 = tt & 15, g4 = (tt >> 4) & 3;
+            for (int ib = wv; ib * 16 < nItems; ib += TEAM / 64)
+                for (int jb = 0; jb * 16 < JW; ++jb) {
+                    const int itemA = ib * 16 + i16, jB = jb * 16 + i16;
+                    const T *fa = fbkSep + (itemA < nItems ? itemA : 0) * a.P;
+                    const T *db = dctT + (jB < JW ? jB : 0) * a.dctPitch;
+                    Acc4<T> acc = {0, 0, 0, 0};
+                    for (int k0 = 0; k0 < a.P; k0 += 4) {
+                        const int k = k0 + g4;
+                        T av = fa[k < a.P ? k : 0], bv = db[k];
+                        av = (itemA < nItems && k < a.P) ? av : (T)0;
+                        bv = jB < JW ? bv : (T)0;
+                        acc = mfma16(av, bv, acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // result rows: 4 g + r in single precision, 4 r + g in double precision
+                        const int item = ib * 16 + (sizeof(T) == 4 ? 4 * g4 + r : 4 * r + g4);
+                        if (item < nItems && jB < JW) feat[item * a.D + jB] = acc[r] * a.mfnorm;
+                    }
+                }
+            team_sync<TEAM>();
+        }
         STAMP(8);
 
         // ---- tile rows -> HBM (static block of every row; delta slots are written later)
