@@ -216,7 +216,8 @@ static int choose_tile(MFCCPlan *p)
     const int lanes = front_lanes(log2nc, pplog);
     // work area of one frame: nc complex points with one pad point per 16, or the nc (t1, ek-t1)
     // pairs followed by the 2 (P+1) segment sums, whichever is larger
-    const int zPitch = (std::max(2 * (nc + nc / 16), 2 * nc + 2 * (c->cfg.bankNum + 1)) + 3) & ~3;
+    const int zPitch = (std::max(std::max(2 * (nc + nc / 16), 2 * nc + 2 * (c->cfg.bankNum + 1)),
+                                 nc + 2 * c->cfg.subBandEFlag) + 3) & ~3; // or nc powers + 2 S band sums
     p->zPitch = zPitch;
     {
         // Per-stage twiddle blocks, laid out as the kernel's fft_stages reads them: for a stage
@@ -372,7 +373,7 @@ static int choose_tile(MFCCPlan *p)
     p->fbkElems = fbkEl;
     p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
     // Lean instantiation: mono 16-bit input, one row, even frame shift, none of the per-frame extras.
-    p->lean = prec == MFCC_PREC_F32 && pplog == 3 && bestTab && p->channels == 1 && p->bps == 2 && V == 1 &&
+    p->lean = prec == MFCC_PREC_F32 && (pplog == 3 || pplog == 4) && bestTab && p->channels == 1 && p->bps == 2 && V == 1 &&
               c->cfg.inc % 2 == 0 && !c->cfg.zeroCrossingFlag && !c->cfg.brightFlag && !c->cfg.subBandEFlag &&
               !c->cfg.fftLength && !c->cfg.zeroMeanSigFlag && !getenv("MFCC_NO_LEAN");
     const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->lean, p->ldsBytes);

@@ -476,7 +476,7 @@ __device__ __forceinline__ void unpack_tile_fast_sel(bool exact, T *rows, const 
 // Registers the compiler may use per lane, as waves per SIMD it has to leave room for.
 constexpr int front_waves_rule(bool f64, int log2nc, int pplog)
 {
-    if (pplog == 4) return f64 ? (log2nc <= 7 ? 2 : 1) : (log2nc <= 9 ? 3 : (log2nc <= 11 ? 2 : 1));
+    if (pplog == 4) return f64 ? (log2nc <= 7 ? 2 : 1) : (log2nc <= 11 ? 2 : 1);
     if (pplog == 3) return f64 ? 2 : 3;
     return f64 ? 3 : 5;
 }
@@ -815,28 +815,46 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 }
                 group_sync<G>();
                 if (F_S > 0) {
+                    // Each band gets a power-of-two share of the frame's lanes: a lane sums its
+                    // part of the band, the shares are folded by lane exchange, one lane per band
+                    // parks the band's two sums behind the power values.
                     const int nseg = F_S;
                     const int width = NC / nseg;
                     const int subAt = a.M + a.c0Flag + a.energyFlag + F_zc + F_bright;
-                    T total = 0, num = 0;
-                    for (int g = 0; g < nseg; ++g) {
-                        const int lo = g * width, hi = (g == nseg - 1) ? NC : lo + width;
+                    int lpb = 1;
+                    while (lpb * 2 * nseg <= G && lpb < 64) lpb *= 2;
+                    const int perPass = G / lpb;
+                    T *bandE = Zt + NC;
+                    for (int b0 = 0; b0 < nseg; b0 += perPass) {
+                        const int b = b0 + l / lpb, sl = l & (lpb - 1);
                         T e = 0, ek = 0;
-                        for (int k = lo + l; k < hi; k += G) {
-                            const T pv = Pw[k];
-                            e += pv;
-                            ek += (T)(k + 1) * pv;
+                        if (b < nseg) {
+                            const int lo = b * width, hi = (b == nseg - 1) ? NC : lo + width;
+                            for (int k = lo + sl; k < hi; k += lpb) {
+                                const T pv = Pw[k];
+                                e += pv;
+                                ek += (T)(k + 1) * pv;
+                            }
                         }
-                        e = group_sum<T, G>(e, red, tt);
-                        ek = group_sum<T, G>(ek, red, tt);
-                        if (active && l == 0) fo[subAt + g] = e;
-                        total += e;
-                        num += ek;
+                        for (int o = lpb >> 1; o > 0; o >>= 1) {
+                            e += __shfl_xor(e, o, 64);
+                            ek += __shfl_xor(ek, o, 64);
+                        }
+                        if (b < nseg && sl == 0) {
+                            bandE[b] = e;
+                            bandE[nseg + b] = ek;
+                        }
                     }
+                    group_sync<G>();
                     if (active && l == 0) {
+                        T total = 0, num = 0;
+                        for (int g = 0; g < nseg; ++g) {
+                            total += bandE[g];
+                            num += bandE[nseg + g];
+                        }
                         if (F_bright)
                             fo[a.M + a.c0Flag + a.energyFlag + F_zc] = num / total / (T)NC;
-                        for (int g = 0; g < F_S; ++g) fo[subAt + g] = fo[subAt + g] / total;
+                        for (int g = 0; g < nseg; ++g) fo[subAt + g] = bandE[g] / total;
                     }
                 }
                 if (active && F_fftLength > 0) {                                   // main.c:247
@@ -1234,7 +1252,7 @@ static int front_occ_t(size_t lds)
 template <typename T, int PL>
 constexpr bool front_has_lean()
 {
-    return sizeof(T) == 4 && PL == 3;
+    return sizeof(T) == 4 && (PL == 3 || PL == 4);
 }
 
 // Dispatch over (precision, log2 nc, points per lane, tables in LDS, lean).  op 0: launch,
