@@ -122,6 +122,10 @@ int MFCCWapperList(const char *iniPath);
  * doubles, row-major, no header. */
 int MFCCWriteFeatures(const char *path, const double *data, long numFrames, int step, int saveType);
 
+/* One value as the text writers print it: "%f" (saveType f) or "%e" (anything else), main.c:276-285,
+ * without the trailing tab.  buf needs at least 400 bytes; returns the length (>= 0) or an error. */
+int MFCCFormatValue(double x, int saveType, char *buf, size_t cap);
+
 /* RIFF/WAVE header walk (README.md:68; replaces loadWAVEFile, main.c:190-191). */
 int MFCCWavInfo(const void *wavFile, size_t wavLen, int *channels, int *sampleRate,
                 int *bytesPerSample, long *numSamples, size_t *dataOffset);

@@ -69,7 +69,7 @@ EXPORTS = [
     "MFCCPlanDestroy", "MFCCShardGeometry", "MFCCPlanTotalRows", "MFCCPlanRowOffset", "MFCCPlanNumFrames",
     "MFCCPlanSampleBegin", "MFCCPlanSampleCount", "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows",
     "MFCCExtractDevice", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
-    "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm",
+    "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm", "MFCCFormatValue",
 ]
 
 
@@ -135,6 +135,7 @@ def lib():
     L.MFCCPlanLastKernelMs.restype = C.c_float
     L.MFCCSynthPcm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_int,
                                C.c_int]
+    L.MFCCFormatValue.argtypes = [C.c_double, C.c_int, C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -196,6 +197,15 @@ def write_features(path, data, save_type):
     rows, st = a.shape
     _check(lib().MFCCWriteFeatures(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_double)),
                                    rows, st, save_type))
+
+
+def format_value(x, save_type):
+    """One value as the text writers print it ("%f" for SAVE_F, "%e" otherwise)."""
+    buf = C.create_string_buffer(400)
+    n = lib().MFCCFormatValue(float(x), save_type, buf, 400)
+    if n < 0:
+        _check(n)
+    return buf.raw[:n].decode()
 
 
 def synth_pcm(num_samples, channels=1, bytes_per_sample=2, seed=0x5EED0000, sample_rate=16000,

@@ -38,4 +38,8 @@ struct WavInfo {
 int wav_parse(const unsigned char *f, size_t len, WavInfo &w);
 int read_file(const char *path, std::vector<unsigned char> &out);
 
+// printf-identical "%f" / "%e" of one value into out (>= 400 bytes); returns the length.
+int fmt_f6(double x, char *out);
+int fmt_e6(double x, char *out);
+
 } // namespace mfcc

@@ -105,20 +105,24 @@ extern "C" int MFCCWriteFeatures(const char *path, const double *data, long numF
     bool ok = true;
     if (text) {
         // "%f\t" / "%e\t" per value, "\n" after every `step` values (main.c:276-285)
-        const char *fmt = saveType == MFCC_SAVE_F ? "%f\t" : "%e\t";
-        std::vector<char> buf;
-        buf.reserve(1 << 20);
-        char tmp[400];
+        // formatted by fmt_f6 / fmt_e6 (printf-identical, several times faster than fprintf)
+        const bool isF = saveType == MFCC_SAVE_F;
+        std::vector<char> buf((1 << 20) + 1024);
+        size_t used = 0;
+        int col = 0;
         for (size_t i = 0; i < n; ++i) {
-            const int len = snprintf(tmp, sizeof tmp, fmt, data[i]);
-            buf.insert(buf.end(), tmp, tmp + len);
-            if ((i + 1) % (size_t)step == 0) buf.push_back('\n');
-            if (buf.size() > (1 << 20) - 512) {
-                ok = ok && fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
-                buf.clear();
+            used += (size_t)(isF ? fmt_f6(data[i], buf.data() + used) : fmt_e6(data[i], buf.data() + used));
+            buf[used++] = '\t';
+            if (++col == step) {
+                buf[used++] = '\n';
+                col = 0;
+            }
+            if (used > (1 << 20)) {
+                ok = ok && fwrite(buf.data(), 1, used, fp) == used;
+                used = 0;
             }
         }
-        if (!buf.empty()) ok = ok && fwrite(buf.data(), 1, buf.size(), fp) == buf.size();
+        if (used) ok = ok && fwrite(buf.data(), 1, used, fp) == used;
     } else {
         if (saveType == MFCC_SAVE_N) {
             // npy v1.0 header as create_npy_header<double> builds it (cnpy.hpp:235-264)

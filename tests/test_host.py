@@ -255,3 +255,46 @@ def test_extraction_needs_a_gpu(tmp_path):
     with pytest.raises(ma.MFCCError) as e:
         ma.wapper(cfg, str(tmp_path / "missing.wav"))
     assert e.value.code == ma.E_OPEN
+
+
+# ---------------------------------------------------------------------------------------------
+# text writers: printf-identical "%f" / "%e" (main.c:276-285) from the exact integer formatter
+# ---------------------------------------------------------------------------------------------
+
+def _special_values():
+    vals = [0.0, -0.0, 1.0, -1.0, 0.5, 9.9999995, 9.99999949999, 99999.9999995, 999999.5, 0.0078125,
+            -0.0234375, 1e-7, 5e-7, 4.999999e-7, 1.5e-6, 2.5e-6, 1e6, 1e7 - 0.5, 123456789.125, 1e14, 1e15,
+            1e21, 9.999999e21, 1e22, 1e-15, 9.9999e-16, 1e-300, 5e-324, 1.7976931348623157e308,
+            float("inf"), float("-inf"), 2.0 ** -20, 2.0 ** -30, 2.0 ** 52, 2.0 ** 53 + 2, 0.1, 0.2, 0.3,
+            1.0 / 3.0, 2.0 / 3.0, 6.02214076e23, 1.602176634e-19, 999999.9999995, 0.9999995, 0.99999949]
+    vals += [k / 128.0 for k in range(1, 64, 2)]          # exact ties of "%f"
+    vals += [(2 * k + 1) / 2.0 ** 12 for k in range(40)]
+    vals += [10.0 ** k for k in range(-15, 22)]
+    vals += [float(np.nextafter(10.0 ** k, 0)) for k in range(-14, 22)]
+    vals += [float(np.nextafter(10.0 ** k, np.inf)) for k in range(-14, 22)]
+    return vals
+
+
+def test_format_value_matches_printf_on_special_values():
+    for x in _special_values():
+        assert ma.format_value(x, ma.SAVE_F) == "%f" % x, x
+        assert ma.format_value(x, ma.SAVE_E) == "%e" % x, x
+        assert ma.format_value(-x, ma.SAVE_F) == "%f" % -x, x
+        assert ma.format_value(-x, ma.SAVE_E) == "%e" % -x, x
+    assert ma.format_value(float("nan"), ma.SAVE_F) in ("nan", "-nan")
+
+
+def test_text_writers_match_printf_in_bulk(tmp_path):
+    rng = np.random.default_rng(20240611)
+    n, step = 6000, 50
+    mant = rng.standard_normal(n * step)
+    expo = rng.integers(-14, 14, n * step)
+    data = (mant * 10.0 ** expo).reshape(n, step)
+    data[::7, 3] = np.round(data[::7, 3] * 128) / 128       # dyadic values: exact ties happen
+    data[::11, 5] = np.float32(data[::11, 5]).astype(np.float64)  # what the f32 path hands over
+    for save_type, spec in ((ma.SAVE_F, "%f"), (ma.SAVE_E, "%e")):
+        path = tmp_path / ("bulk." + spec[1])
+        ma.write_features(str(path), data, save_type)
+        got = path.read_bytes()
+        want = "".join("".join(spec % v + "\t" for v in row) + "\n" for row in data).encode()
+        assert got == want
