@@ -23,11 +23,15 @@ static uint32_t le16(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_
 // (README.md:68 allows extra chunks between the 44-byte header and the data chunk).
 int wav_parse(const unsigned char *f, size_t len, WavInfo &w)
 {
-    if (!f || len < 12 || memcmp(f, "RIFF", 4) != 0 || memcmp(f + 8, "WAVE", 4) != 0)
+    // RF64 (EBU Tech 3306): same layout, 64-bit sizes in a leading "ds64" chunk, for files whose
+    // data would overflow the 32-bit size fields
+    const bool rf64 = f && len >= 12 && memcmp(f, "RF64", 4) == 0;
+    if (!f || len < 12 || (memcmp(f, "RIFF", 4) != 0 && !rf64) || memcmp(f + 8, "WAVE", 4) != 0)
         return set_error("not a RIFF/WAVE file"), MFCC_E_WAV;
     size_t pos = 12;
     bool haveFmt = false;
     int blockAlign = 0;
+    uint64_t dataSize64 = 0;
     while (pos + 8 <= len) {
         const uint32_t sz = le32(f + pos + 4);
         const unsigned char *body = f + pos + 8;
@@ -36,6 +40,9 @@ int wav_parse(const unsigned char *f, size_t len, WavInfo &w)
             const uint32_t tag = le16(body);
             if (tag != 1 && tag != 0xFFFE)
                 return set_error("WAVE format tag %u is not PCM", tag), MFCC_E_WAV;
+            // WAVE_FORMAT_EXTENSIBLE: the sub-format GUID starts with the real format tag
+            if (tag == 0xFFFE && sz >= 40 && pos + 8 + 40 <= len && le16(body + 24) != 1)
+                return set_error("extensible WAVE sub-format %u is not PCM", le16(body + 24)), MFCC_E_WAV;
             w.channels = (int)le16(body + 2);
             w.sampleRate = (int)le32(body + 4);
             blockAlign = (int)le16(body + 12);
@@ -48,9 +55,13 @@ int wav_parse(const unsigned char *f, size_t len, WavInfo &w)
             if (blockAlign != w.channels * w.bytesPerSample)
                 return set_error("block align %d != channels x sample size", blockAlign), MFCC_E_WAV;
             haveFmt = true;
+        } else if (rf64 && !memcmp(f + pos, "ds64", 4)) {
+            if (sz < 24 || pos + 8 + 24 > len) return set_error("short ds64 chunk"), MFCC_E_WAV;
+            dataSize64 = (uint64_t)le32(body + 8) | ((uint64_t)le32(body + 12) << 32);
         } else if (!memcmp(f + pos, "data", 4)) {
             if (!haveFmt) return set_error("data chunk before fmt chunk"), MFCC_E_WAV;
             size_t bytes = sz, avail = len - (pos + 8);
+            if (rf64 && sz == 0xFFFFFFFFu) bytes = (size_t)dataSize64;
             if (bytes > avail) bytes = avail; // size field that overflowed or was never patched
             w.numSamples = (long)(bytes / (size_t)blockAlign);
             w.dataOffset = pos + 8;

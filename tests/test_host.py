@@ -298,3 +298,24 @@ def test_text_writers_match_printf_in_bulk(tmp_path):
         got = path.read_bytes()
         want = "".join("".join(spec % v + "\t" for v in row) + "\n" for row in data).encode()
         assert got == want
+
+
+def test_wav_rf64_and_extensible():
+    import struct
+    pcm = bytes(ma.synth_pcm(500, 2, 2, seed=11))
+    fmt = struct.pack("<HHIIHH", 1, 2, 48000, 48000 * 4, 4, 16)
+    ds64 = struct.pack("<QQQI", 0, len(pcm), 500, 0)
+    rf64 = (b"RF64" + struct.pack("<I", 0xFFFFFFFF) + b"WAVE" + b"ds64" + struct.pack("<I", len(ds64)) + ds64 +
+            b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", 0xFFFFFFFF) + pcm)
+    info = ma.wav_info(rf64)
+    assert (info["numSamples"], info["channels"], info["sampleRate"]) == (500, 2, 48000)
+    assert rf64[info["dataOffset"]:info["dataOffset"] + 8] == pcm[:8]
+    # WAVE_FORMAT_EXTENSIBLE with the PCM sub-format is accepted, with the float sub-format refused
+    def extensible(sub):
+        body = struct.pack("<HHIIHHHHIH", 0xFFFE, 2, 48000, 48000 * 4, 4, 16, 22, 16, 3, sub) + b"\0" * 14
+        return (b"RIFF" + struct.pack("<I", 4 + 8 + len(body) + 8 + len(pcm)) + b"WAVE" + b"fmt " +
+                struct.pack("<I", len(body)) + body + b"data" + struct.pack("<I", len(pcm)) + pcm)
+    assert ma.wav_info(extensible(1))["numSamples"] == 500
+    with pytest.raises(ma.MFCCError) as e:
+        ma.wav_info(extensible(3))
+    assert e.value.code == ma.E_WAV
