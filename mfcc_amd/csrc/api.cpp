@@ -205,9 +205,15 @@ static int choose_tile(MFCCPlan *p)
     const MFCCContext *c = p->ctx;
     const int V = c->cfg.vecNum, log2nc = c->tab.log2nc, prec = c->cfg.precision;
     const int nc = c->tab.nc, P = c->cfg.bankNum;
-    // complex points per lane = 2^pplog: 8 points (radix-8 stages) measured fastest on MI355X
-    // where that variant exists, 16 otherwise
-    int pplog = front_variant_exists(log2nc, 3) ? 3 : 4;
+    // complex points per lane = 2^pplog: for the general kernel 8 points (radix-8 stages) measured
+    // fastest on MI355X where that variant exists, 16 otherwise
+    // Lean candidates (see k_front) run 16 points per lane at two workgroups per CU: measured
+    // slightly ahead of 8 points at three (6.46 vs 6.63 ms on 10,000 ten-second utterances).
+    const bool leanCand = prec == MFCC_PREC_F32 && p->channels == 1 && p->bps == 2 && V == 1 &&
+                          c->cfg.inc % 2 == 0 && !c->cfg.zeroCrossingFlag && !c->cfg.brightFlag &&
+                          !c->cfg.subBandEFlag && !c->cfg.fftLength && !c->cfg.zeroMeanSigFlag &&
+                          !getenv("MFCC_NO_LEAN");
+    int pplog = (front_variant_exists(log2nc, 3) && !leanCand) ? 3 : 4;
     if (const char *e = getenv("MFCC_PPLOG")) // tuning aid
         if (front_variant_exists(log2nc, atoi(e))) pplog = atoi(e);
     p->pplog = pplog;
@@ -373,9 +379,7 @@ static int choose_tile(MFCCPlan *p)
     p->fbkElems = fbkEl;
     p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
     // Lean instantiation: mono 16-bit input, one row, even frame shift, none of the per-frame extras.
-    p->lean = prec == MFCC_PREC_F32 && (pplog == 3 || pplog == 4) && bestTab && p->channels == 1 && p->bps == 2 && V == 1 &&
-              c->cfg.inc % 2 == 0 && !c->cfg.zeroCrossingFlag && !c->cfg.brightFlag && !c->cfg.subBandEFlag &&
-              !c->cfg.fftLength && !c->cfg.zeroMeanSigFlag && !getenv("MFCC_NO_LEAN");
+    p->lean = leanCand && (pplog == 3 || pplog == 4) && bestTab;
     const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->lean, p->ldsBytes);
     if (getenv("MFCC_DEBUG"))
         fprintf(stderr, "mfcc plan: points/lane %d, teams %d, lean %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",

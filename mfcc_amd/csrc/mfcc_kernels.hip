@@ -224,9 +224,46 @@ using LanePoints = cpx<T>[Geo<LOG2NC, PPLOG>::PPL]; // the complex points one la
 // Twiddles are stored per stage, [r-1][j mod NS] = exp(-2 pi i r (j mod NS) / (NS R)), so that the
 // lanes of a wave read consecutive (or identical) 8-byte words: no LDS bank conflicts.  TWOFF is
 // the complex offset of this stage's block in that table (the blocks follow each other).
-template <typename T, int LOG2NC, int PPLOG, int LOGNS, int TWOFF, bool TWLDS>
+// TWREG: the lane's twiddles of all stages were loaded once into the register array twr (see
+// fft_load_twiddles); TWR is this stage's first entry there.
+
+// Twiddle factors one lane uses over all stages: (R - 1) per butterfly of every stage but the first.
+template <int LOG2NC, int PPLOG>
+constexpr int fft_twiddle_regs()
+{
+    using GEO = Geo<LOG2NC, PPLOG>;
+    int n = 0;
+    for (int logns = 0; logns < LOG2NC;) {
+        const int rb = (LOG2NC - logns) < GEO::RBMAX ? (LOG2NC - logns) : GEO::RBMAX;
+        if (logns > 0) n += (GEO::PPL >> rb) * ((1 << rb) - 1);
+        logns += rb;
+    }
+    return n > 0 ? n : 1;
+}
+
+template <typename T, int LOG2NC, int PPLOG, int LOGNS = 0, int TWOFF = 0, int TWR = 0>
+__device__ __forceinline__ void fft_load_twiddles(cpx<T> *twr, int l, const cpx<T> *tw)
+{
+    using GEO = Geo<LOG2NC, PPLOG>;
+    constexpr int G = GEO::G, PPL = GEO::PPL;
+    constexpr int RB = (LOG2NC - LOGNS) < GEO::RBMAX ? (LOG2NC - LOGNS) : GEO::RBMAX;
+    constexpr int R = 1 << RB, NS = 1 << LOGNS, NB = PPL / R;
+    if constexpr (LOGNS > 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int m = (l + G * b) & (NS - 1);
+#pragma unroll
+            for (int r = 1; r < R; ++r) twr[TWR + b * (R - 1) + r - 1] = tw[TWOFF + (r - 1) * NS + m];
+        }
+    }
+    if constexpr (LOGNS + RB < LOG2NC)
+        fft_load_twiddles<T, LOG2NC, PPLOG, LOGNS + RB, TWOFF + (LOGNS > 0 ? (R - 1) * NS : 0),
+                          TWR + (LOGNS > 0 ? NB * (R - 1) : 0)>(twr, l, tw);
+}
+
+template <typename T, int LOG2NC, int PPLOG, int LOGNS, int TWOFF, bool TWLDS, bool TWREG = false, int TWR = 0>
 __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<T> *Z, int l,
-                                           const cpx<T> *tw)
+                                           const cpx<T> *tw, const cpx<T> *twr = nullptr)
 {
     using GEO = Geo<LOG2NC, PPLOG>;
     constexpr int NC = GEO::NC, G = GEO::G, PPL = GEO::PPL;
@@ -248,7 +285,10 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
         for (int b = 0; b < NB; ++b) {
             const int m = (l + G * b) & (NS - 1);
             cpx<T> w[R > 1 ? R - 1 : 1];
-            if constexpr (sizeof(T) == 4 && TWLDS && R > 1) {
+            if constexpr (TWREG) {
+#pragma unroll
+                for (int r = 1; r < R; ++r) w[r - 1] = twr[TWR + b * (R - 1) + r - 1];
+            } else if constexpr (sizeof(T) == 4 && TWLDS && R > 1) {
                 lds_read_strided<R - 1, NS * 8>(w, &tw[TWOFF + m]);
             } else {
 #pragma unroll
@@ -270,7 +310,8 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
     }
     group_sync<G>();
     if constexpr (LOGNS + RB < LOG2NC)
-        fft_stages<T, LOG2NC, PPLOG, LOGNS + RB, TWOFF + (LOGNS > 0 ? (R - 1) * NS : 0), TWLDS>(v, Z, l, tw);
+        fft_stages<T, LOG2NC, PPLOG, LOGNS + RB, TWOFF + (LOGNS > 0 ? (R - 1) * NS : 0), TWLDS, TWREG,
+                   TWR + (LOGNS > 0 ? NB * (R - 1) : 0)>(v, Z, l, tw, twr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -572,6 +613,12 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         }
     }
 
+    // With 16 points per lane the kernel runs at two waves per SIMD: the 256-register budget also
+    // holds the lane's twiddle factors.
+    constexpr bool TWREG = LEAN && PPLOG == 4;
+    cpx<T> twr[TWREG ? fft_twiddle_regs<LOG2NC, PPLOG>() : 1];
+    if constexpr (TWREG) fft_load_twiddles<T, LOG2NC, PPLOG>(twr, l, reinterpret_cast<const cpx<T> *>(tw));
+
     STAMP_DECL
     STAMP_START;
     for (int tile = blockIdx.x * NTEAMS + team; tile < a.numTiles; tile += gridDim.x * NTEAMS) {
@@ -737,7 +784,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             }
 
             // ---- nc-point complex FFT of z[n] = x[2n] + i x[2n+1]   (Realft mfcc.c:262-270)
-            if (!SKIP(2)) fft_stages<T, LOG2NC, PPLOG, 0, 0, TLDS>(v, Z, l, reinterpret_cast<const cpx<T> *>(tw));
+            if (!SKIP(2))
+                fft_stages<T, LOG2NC, PPLOG, 0, 0, TLDS, TWREG>(v, Z, l, reinterpret_cast<const cpx<T> *>(tw), twr);
             STAMP(3);
 
             // ---- real-FFT split and power  (mfcc.c:274-290, ek of mfcc.c:153-155)
