@@ -48,7 +48,12 @@ struct MFCCPlan {
     int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0, teamElems = 0, numRegBlocks = 0;
     int tabElems = 0, winPad = 0, featElems = 0, fbkElems = 0, rowTail = 0;
     int blocksPerCu = 1, numCus = 256, pplog = 4;
-    bool lean = false;
+    int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
+    std::vector<float> melW;
+    std::vector<int32_t> melMeta;
+    int melSteps = 0;
+    float *dMelW = nullptr;
+    int32_t *dMelMeta = nullptr;
     size_t ldsBytes = 0;
     UttDesc *dUtts = nullptr;
     int32_t *dTileUtt = nullptr, *dChunkUtt = nullptr, *dLaneSeg = nullptr, *dRegUtt = nullptr;
@@ -222,7 +227,7 @@ static int choose_tile(MFCCPlan *p)
     const int lanes = front_lanes(log2nc, pplog);
     // work area of one frame: nc complex points with one pad point per 16, or the nc (t1, ek-t1)
     // pairs followed by the 2 (P+1) segment sums, whichever is larger
-    const int zPitch = (std::max(std::max(2 * (nc + nc / 16), 2 * nc + 2 * (c->cfg.bankNum + 1)),
+    int zPitch = (std::max(std::max(2 * (nc + nc / 16), 2 * nc + 2 * (c->cfg.bankNum + 1)),
                                  nc + 2 * c->cfg.subBandEFlag) + 3) & ~3; // or nc powers + 2 S band sums
     p->zPitch = zPitch;
     {
@@ -312,6 +317,105 @@ static int choose_tile(MFCCPlan *p)
             fprintf(stderr, "mfcc plan: mel rounds %d, modelled LDS cycles per frame pair %d\n", p->maxSeg, total);
         }
     }
+    // Matrix-core mel filterbank (kernel mode 2): 16 blocks of 4 lanes, each with 4 consecutive
+    // channels ("quad") and a contiguous run of the bins that touch them; the 16 - quads spare
+    // blocks halve the longest runs.  Possible when a frame fills at most a quarter wave
+    // (256..1024 complex points at 16 points per lane) and every run fits kMelSteps.
+    p->melSteps = 0;
+    if (leanCand && pplog == 4 && log2nc >= 8 && log2nc <= 10 && !getenv("MFCC_NO_MELM")) {
+        const int P1 = P + 1, NQ = (P + 3) / 4;
+        std::vector<int> sb(P1, 0), se(P1, 0);
+        for (int k = 0; k < nc; ++k) {
+            const int ch = c->tab.loChan[k];
+            if (ch < 0 || ch >= P1) continue;
+            if (se[ch] == 0) sb[ch] = k;
+            se[ch] = k + 1;
+        }
+        struct Piece { int quad, k0, k1, second; };
+        std::vector<Piece> pieces;
+        for (int q = 0; q < NQ && NQ <= 16; ++q) {
+            int k0 = nc, k1 = 0; // bins of segments 4q .. 4q+4: they reach channels 4q .. 4q+3
+            for (int sIdx = 4 * q; sIdx <= std::min(4 * q + 4, P); ++sIdx)
+                if (se[sIdx] > sb[sIdx]) k0 = std::min(k0, sb[sIdx]), k1 = std::max(k1, se[sIdx]);
+            if (k1 < k0) k0 = k1 = 0;
+            pieces.push_back({q, k0, k1, 0});
+        }
+        std::vector<char> split(NQ, 0);
+        for (int spare = 16 - NQ; spare > 0 && NQ <= 16; --spare) {
+            int best = -1;
+            for (size_t i = 0; i < pieces.size(); ++i)
+                if (!split[pieces[i].quad] && pieces[i].k1 - pieces[i].k0 > 1 &&
+                    (best < 0 || pieces[i].k1 - pieces[i].k0 > pieces[best].k1 - pieces[best].k0))
+                    best = (int)i;
+            if (best < 0) break;
+            const Piece whole = pieces[best];
+            const int mid = whole.k0 + (whole.k1 - whole.k0 + 1) / 2;
+            split[whole.quad] = 1;
+            pieces[best] = {whole.quad, whole.k0, mid, 0};
+            pieces.insert(pieces.begin() + best + 1, {whole.quad, mid, whole.k1, 1});
+        }
+        // Every block reads `steps` consecutive bins from r0 <= k0 (r0 + steps >= k1, inside the
+        // frame).  The 32 lanes of a half wave (8 blocks x 4 frame slots, slots 8 banks apart)
+        // hit 32 different LDS banks when the 8 blocks' r0 differ modulo 8: take the smallest
+        // `steps` for which such starts exist (first fit, blocks with the fewest possible starts first).
+        int longest = 0;
+        for (const Piece &pc : pieces) longest = std::max(longest, pc.k1 - pc.k0);
+        std::vector<int> r0(pieces.size(), 0);
+        int steps = 0;
+        for (int trial = std::max(longest, 1); trial <= std::min(kMelSteps, nc) && NQ <= 16 && !steps; ++trial) {
+            std::vector<size_t> order(pieces.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+            auto choices = [&](size_t b) {
+                return std::min(pieces[b].k0, nc - trial) - std::max(0, pieces[b].k1 - trial);
+            };
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return choices(x) < choices(y); });
+            char used[2][8] = {{0}};
+            bool ok = true;
+            for (size_t b : order) {
+                const int lo = std::max(0, pieces[b].k1 - trial), hi = std::min(pieces[b].k0, nc - trial);
+                int pick = -1;
+                for (int r = hi; r >= lo && pick < 0; --r)
+                    if (!used[b / 8][r & 7]) pick = r;
+                if (pick < 0) {
+                    ok = false;
+                    break;
+                }
+                used[b / 8][pick & 7] = 1;
+                r0[b] = pick;
+            }
+            if (ok) steps = trial;
+        }
+        if (steps >= 1) {
+            p->melSteps = steps;
+            p->melW.assign((size_t)steps * 64, 0.0f);
+            p->melMeta.assign(64 * 4, 0);
+            for (int ln = 0; ln < 64; ++ln) p->melMeta[4 * ln + 2] = -1;
+            for (size_t b = 0; b < pieces.size(); ++b) {
+                const Piece &pc = pieces[b];
+                const bool owner = pc.second || !split[pc.quad];
+                for (int j = 0; j < 4; ++j) {
+                    const int ln = 4 * (int)b + j, ch = 4 * pc.quad + j;
+                    p->melMeta[4 * ln + 0] = r0[b];
+                    p->melMeta[4 * ln + 1] = (pc.second ? 1 : 0) | (owner ? 2 : 0);
+                    p->melMeta[4 * ln + 2] = (owner && ch < P) ? ch : -1;
+                    if (ch >= P) continue;
+                    for (int t = 0; t < steps; ++t) {
+                        const int k = r0[b] + t;
+                        if (k < pc.k0 || k >= pc.k1) continue;
+                        const int sIdx = c->tab.loChan[k]; // mfcc.c:158-163: loWt to channel s, the rest to s+1
+                        double w = 0.0;
+                        if (sIdx == ch + 1) w = c->tab.loWt[k];
+                        if (sIdx == ch) w = 1.0 - c->tab.loWt[k];
+                        p->melW[(size_t)t * 64 + ln] = (float)w;
+                    }
+                }
+            }
+            // frame slots 8 banks apart: work-area pitch = 8 (mod 32) elements
+            zPitch = ((zPitch + 23) & ~31) + 8;
+            p->zPitch = zPitch;
+            if (getenv("MFCC_DEBUG")) fprintf(stderr, "mfcc plan: matrix-core mel, %d steps (longest run %d)\n", steps, longest);
+        }
+    }
     const size_t el = prec == MFCC_PREC_F64 ? 8 : 4;
     const int bpi = p->channels * p->bps;
     const int base = (groups + V - 1) / V;
@@ -379,11 +483,11 @@ static int choose_tile(MFCCPlan *p)
     p->fbkElems = fbkEl;
     p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
     // Lean instantiation: mono 16-bit input, one row, even frame shift, none of the per-frame extras.
-    p->lean = leanCand && (pplog == 3 || pplog == 4) && bestTab;
-    const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->lean, p->ldsBytes);
+    p->mode = (leanCand && (pplog == 3 || pplog == 4) && bestTab) ? (p->melSteps > 0 ? 2 : 1) : 0;
+    const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->mode, p->ldsBytes);
     if (getenv("MFCC_DEBUG"))
-        fprintf(stderr, "mfcc plan: points/lane %d, teams %d, lean %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
-                1 << pplog, teams, (int)p->lean, bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
+        fprintf(stderr, "mfcc plan: points/lane %d, teams %d, mode %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
+                1 << pplog, teams, p->mode, bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
     if (occ > 0 && occ < p->blocksPerCu) p->blocksPerCu = occ;
     if (const char *e = getenv("MFCC_BLOCKS_PER_CU")) // tuning aid: resident workgroups per CU
         if (atoi(e) > 0) p->blocksPerCu = atoi(e);
@@ -466,6 +570,12 @@ static int finish_plan(MFCCPlan *p)
     }
     HIP_TRY(hipMalloc((void **)&p->dLaneSeg, std::max<size_t>(p->laneSeg.size(), 4) * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p->dLaneSeg, p->laneSeg.data(), p->laneSeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (p->mode == 2) {
+        HIP_TRY(hipMalloc((void **)&p->dMelW, p->melW.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(p->dMelW, p->melW.data(), p->melW.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&p->dMelMeta, p->melMeta.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(p->dMelMeta, p->melMeta.data(), p->melMeta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     const bool needStats = c->cfg.znormFlag != 0;
     if (needStats) {
         HIP_TRY(hipMalloc((void **)&p->dChunkUtt, std::max<size_t>(chunkUtt.size(), 1) * sizeof(int32_t)));
@@ -601,6 +711,8 @@ extern "C" void MFCCPlanDestroy(MFCCPlan *p)
     (void)hipFree(p->dTileUtt);
     (void)hipFree(p->dTiles);
     (void)hipFree(p->dRegUtt);
+    (void)hipFree(p->dMelW);
+    (void)hipFree(p->dMelMeta);
     (void)hipFree(p->dChunkUtt);
     (void)hipFree(p->dLaneSeg);
     (void)hipFree(p->dStageTw);
@@ -662,7 +774,10 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.utts = p->dUtts;
     a.tileUtt = p->dTileUtt;
     a.zeroMean = c->cfg.zeroMeanSigFlag ? 1 : 0;
-    a.lean = p->lean ? 1 : 0;
+    a.lean = p->mode;
+    a.melW = p->dMelW;
+    a.melMeta = p->dMelMeta;
+    a.melSteps = p->melSteps;
     a.out = static_cast<T *>(outDev);
     a.numTiles = p->numTiles;
     a.wlen = c->cfg.wlen;

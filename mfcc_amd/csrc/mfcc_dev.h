@@ -9,6 +9,7 @@ constexpr int kBlock = 256;       // threads per workgroup of every kernel (4 wa
 constexpr int kMaxLog2Nc = 13;    // fftN <= 16384
 constexpr int kStatRows = 1024;   // rows per workgroup of the z-norm statistics kernels
 constexpr int kRegRows = 64;      // rows per workgroup pass of the regression kernel
+constexpr int kMelSteps = 44;     // most bins one block of the matrix-core mel filterbank walks
 
 // One utterance (or one rank's shard of a long recording) as the kernels see it.
 struct UttDesc {
@@ -44,7 +45,11 @@ struct FrontArgs {
     const UttDesc *utts;      // read only for the row means (zeroMean != 0)
     const int32_t *tileUtt;   // utterance of each tile (read only if zeroMean != 0)
     int zeroMean;
-    int lean;                 // 1: the lean instantiation's promises hold (see k_front)
+    int lean;                 // kernel mode: 0 general, 1 lean, 2 lean with the matrix-core mel filterbank
+    const float *melW;        // mode 2: melSteps x 64 weights, [step][lane]
+    const int32_t *melMeta;   // mode 2: 64 x {first bin of the lane's block, flags (1: add the block
+                              // before, 2: writes results), channel or -1, 0}
+    int melSteps;
     T *out;
     int numTiles;
     int wlen, inc, framesPerTile;
@@ -105,7 +110,7 @@ int front_groups(int log2nc, int pplog);          // frames in flight per workgr
 int front_teams(int log2nc, int pplog);           // independent teams (tile streams) per workgroup
 int front_lanes(int log2nc, int pplog);           // lanes that share one frame
 int front_waves_limit(int precision, int log2nc, int pplog); // waves per SIMD the kernel is compiled for
-int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, bool lean, size_t ldsBytes);
+int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, int mode, size_t ldsBytes);
 int launch_regress(int precision, const void *args, int numBlocks, void *stream);
 int launch_colstats(int precision, const void *args, int numChunks, void *stream);
 int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream);

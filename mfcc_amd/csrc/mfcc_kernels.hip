@@ -531,7 +531,7 @@ constexpr int front_waves_per_simd()
 // Fused static-feature kernel.  TLDS: window / twiddle / split tables are staged in LDS.
 // ------------------------------------------------------------------------------------------
 
-template <typename T, int LOG2NC, int PPLOG, bool TLDS, bool LEAN>
+template <typename T, int LOG2NC, int PPLOG, bool TLDS, int MODE>
 __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>())) void k_front(
     const FrontArgs<T> a)
 {
@@ -542,6 +542,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     constexpr int NPAIR = PPL / 2 > 0 ? PPL / 2 : 1;
     constexpr int VEC = 16 / (int)sizeof(T); // elements of one 16-byte store
 
+    // MODE 0: general.  MODE >= 1 (LEAN), MODE 2 (MELM): see below.
+    constexpr bool LEAN = MODE >= 1, MELM = MODE == 2;
     // LEAN: the host promises mono 16-bit input, one derived row, even frame shift and none of
     // the zero-crossing / brightness / sub-band / magnitude / zero-mean options, so those paths
     // (and the registers they pin) are compiled out.
@@ -607,10 +609,30 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         for (int q = 0; q < NPAIR; ++q) {
             const int k = l + G * q;
             const int k2 = k == 0 ? NC / 2 : NC - k;
-            lwreg[2 * q] = lw[k];
-            lwreg[2 * q + 1] = lw[NC > 1 ? k2 : 0];
+            if constexpr (!MELM) {
+                lwreg[2 * q] = lw[k];
+                lwreg[2 * q + 1] = lw[NC > 1 ? k2 : 0];
+            }
             swreg[q] = reinterpret_cast<const cpx<T> *>(split)[k];
         }
+    }
+    // MELM: the mel filterbank of the team's frames in flight as 4 x 4 x 1 matrix-core products.
+    // The 64 lanes form 16 blocks of 4; block b owns 4 consecutive channels and a contiguous bin
+    // range.  Per step t lane (b, i) feeds the power of frame slot i at bin r0_b + t and the weight
+    // of that bin for channel 4 q_b + i; element r of the result is frame slot r's sum for the
+    // lane's channel.  Wide channel groups are cut over two neighbouring blocks, added at the end.
+    // The lane's weights stay in registers; r0, the role flags and the channel come from melMeta.
+    float melW[MELM ? kMelSteps : 1];
+    const T *melA = zbuf;
+    int melFlags = 0, melCh = -1;
+    if constexpr (MELM) {
+        const int lane = tid & 63;
+#pragma unroll
+        for (int t = 0; t < kMelSteps; ++t) melW[t] = t < a.melSteps ? a.melW[t * 64 + lane] : 0.0f;
+        const int4 mm = reinterpret_cast<const int4 *>(a.melMeta)[lane];
+        melA = zbuf + ((lane & 3) < GT ? (lane & 3) : 0) * a.zPitch + mm.x;
+        melFlags = mm.y;
+        melCh = mm.z;
     }
 
     // With 16 points per lane the kernel runs at two waves per SIMD: the 256-register budget also
@@ -919,6 +941,46 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     fo[a.M + a.c0Flag + a.energyFlag] = (T)zc / (T)(a.wlen - 1);   // main.c:244
             }
 
+            if constexpr (MELM) {
+                // plain power values of the frame into its work area, bin order
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) {
+                    const int k = l + G * q;
+                    const int k2 = k == 0 ? NC / 2 : NC - k;
+                    Pw[k] = pa[q];
+                    Pw[k2] = pb[q];
+                }
+                team_sync<TEAM>();
+                STAMP(5);
+                Acc4<float> macc = {0, 0, 0, 0};
+                const bool slotLive = (tt & 3) < GT;
+                // always kMelSteps steps, straight-line so that the loads run ahead of the products:
+                // the weights are zero past the plan's steps, and the extra bins read there are
+                // finite values of the same work area
+                float av[kMelSteps];
+#pragma unroll
+                for (int t = 0; t < kMelSteps; ++t) av[t] = melA[t];
+#pragma unroll
+                for (int t = 0; t < kMelSteps; ++t)
+                    macc = __builtin_amdgcn_mfma_f32_4x4x1f32(slotLive ? av[t] : 0.0f, melW[t], macc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { // second block of a pair adds the first block's part
+                    const float other = __shfl_up(macc[r], 4, 64);
+                    macc[r] += (melFlags & 1) ? other : 0.0f;
+                }
+                if ((melFlags & 2) && melCh >= 0) { // owner of channel melCh: log(max(., 1)), mfcc.c:171-176
+#pragma unroll
+                    for (int r = 0; r < GT; ++r) {
+                        const int it2 = base + r;
+                        if (it2 < nItems) {
+                            const T lv = tlog<T>(macc[r] < 1.0f ? (T)1 : (T)macc[r]);
+                            if (a.fbkElems) fbkSep[it2 * a.P + melCh] = lv;
+                            if (a.fbankFlag) feat[it2 * a.D + melCh] = lv;
+                        }
+                    }
+                }
+                team_sync<TEAM>();
+            } else {
             // Per bin, exactly the two products of mfcc.c:160-162: t1 = loWt*ek and ek - t1.
             if (SKIP(4)) {
                 asm volatile("" ::"v"(pa[0]), "v"(pb[NPAIR - 1]));
@@ -969,6 +1031,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             }
             group_sync<G>();
 
+            }
             STAMP(6);
             // the next round overwrites the work area: every lane of the frame is done with it
             group_sync<G>();
@@ -1270,28 +1333,28 @@ __global__ void k_uttmeans(UttDesc *utts, int numUtts, const unsigned long long 
         if (e_ != hipSuccess) return (int)e_; \
     } while (0)
 
-template <typename T, int L, int PL, bool TLDS, bool LEAN>
+template <typename T, int L, int PL, bool TLDS, int MODE>
 static int launch_front_t(const FrontArgs<T> &a, int numBlocks, size_t lds, hipStream_t st)
 {
     static bool attrSet[16] = {};
     int dev = 0;
     MFCC_HIP_OK(hipGetDevice(&dev));
     if (dev < 16 && !attrSet[dev]) {
-        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS, LEAN>),
+        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS, MODE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attrSet[dev] = true;
     }
-    hipLaunchKernelGGL((k_front<T, L, PL, TLDS, LEAN>), dim3(numBlocks), dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((k_front<T, L, PL, TLDS, MODE>), dim3(numBlocks), dim3(kBlock), lds, st, a);
     return (int)hipGetLastError();
 }
 
-template <typename T, int L, int PL, bool TLDS, bool LEAN>
+template <typename T, int L, int PL, bool TLDS, int MODE>
 static int front_occ_t(size_t lds)
 {
     int n = 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS, LEAN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_front<T, L, PL, TLDS, LEAN>, kBlock, lds) != hipSuccess)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_front<T, L, PL, TLDS, MODE>, kBlock, lds) != hipSuccess)
         return 0;
     return n;
 }
@@ -1303,30 +1366,37 @@ constexpr bool front_has_lean()
     return sizeof(T) == 4 && (PL == 3 || PL == 4);
 }
 
-// Dispatch over (precision, log2 nc, points per lane, tables in LDS, lean).  op 0: launch,
-// op 1: occupancy.
+// Dispatch over (precision, log2 nc, points per lane, tables in LDS, mode).  op 0: launch,
+// op 1: occupancy.  mode 1 (lean) exists for single precision with 8 or 16 points per lane and
+// tables in LDS; mode 2 (lean + matrix-core mel) for 16 points per lane and 256..1024 complex points.
 template <typename T, int L, int PL>
-static int front_do(int op, bool tl, bool lean, const void *args, int numBlocks, size_t lds, hipStream_t st)
+static int front_do(int op, bool tl, int mode, const void *args, int numBlocks, size_t lds, hipStream_t st)
 {
     if constexpr (front_has_lean<T, PL>()) {
-        if (lean && tl) {
-            if (op == 1) return front_occ_t<T, L, PL, true, true>(lds);
-            return launch_front_t<T, L, PL, true, true>(*static_cast<const FrontArgs<T> *>(args), numBlocks, lds, st);
+        if constexpr (PL == 4 && L >= 8 && L <= 10) {
+            if (mode == 2 && tl) {
+                if (op == 1) return front_occ_t<T, L, PL, true, 2>(lds);
+                return launch_front_t<T, L, PL, true, 2>(*static_cast<const FrontArgs<T> *>(args), numBlocks, lds, st);
+            }
+        }
+        if (mode >= 1 && tl) {
+            if (op == 1) return front_occ_t<T, L, PL, true, 1>(lds);
+            return launch_front_t<T, L, PL, true, 1>(*static_cast<const FrontArgs<T> *>(args), numBlocks, lds, st);
         }
     }
-    if (op == 1) return tl ? front_occ_t<T, L, PL, true, false>(lds) : front_occ_t<T, L, PL, false, false>(lds);
+    if (op == 1) return tl ? front_occ_t<T, L, PL, true, 0>(lds) : front_occ_t<T, L, PL, false, 0>(lds);
     const FrontArgs<T> &a = *static_cast<const FrontArgs<T> *>(args);
-    return tl ? launch_front_t<T, L, PL, true, false>(a, numBlocks, lds, st)
-              : launch_front_t<T, L, PL, false, false>(a, numBlocks, lds, st);
+    return tl ? launch_front_t<T, L, PL, true, 0>(a, numBlocks, lds, st)
+              : launch_front_t<T, L, PL, false, 0>(a, numBlocks, lds, st);
 }
 
 template <typename T>
-static int front_dispatch(int op, int log2nc, int pplog, bool tl, bool lean, const void *args, int numBlocks,
+static int front_dispatch(int op, int log2nc, int pplog, bool tl, int mode, const void *args, int numBlocks,
                           size_t lds, hipStream_t st)
 {
     switch (log2nc * 8 + pplog) {
 #define MFCC_CASE(L, PL) \
-    case L * 8 + PL: return front_do<T, L, PL>(op, tl, lean, args, numBlocks, lds, st);
+    case L * 8 + PL: return front_do<T, L, PL>(op, tl, mode, args, numBlocks, lds, st);
         MFCC_CASE(1, 4) MFCC_CASE(2, 4) MFCC_CASE(3, 4) MFCC_CASE(4, 4) MFCC_CASE(5, 4)
         MFCC_CASE(6, 4) MFCC_CASE(7, 4) MFCC_CASE(8, 4) MFCC_CASE(9, 4) MFCC_CASE(10, 4)
         MFCC_CASE(11, 4) MFCC_CASE(12, 4) MFCC_CASE(13, 4)
@@ -1352,16 +1422,16 @@ int launch_front(int precision, int log2nc, int pplog, const void *args, int num
     if (numBlocks <= 0) return 0;
     const bool tl = precision == 1 ? static_cast<const FrontArgs<double> *>(args)->tabElems > 0
                                    : static_cast<const FrontArgs<float> *>(args)->tabElems > 0;
-    const bool lean = precision == 1 ? false : static_cast<const FrontArgs<float> *>(args)->lean != 0;
-    return precision == 1 ? front_dispatch<double>(0, log2nc, pplog, tl, false, args, numBlocks, ldsBytes, st)
-                          : front_dispatch<float>(0, log2nc, pplog, tl, lean, args, numBlocks, ldsBytes, st);
+    const int mode = precision == 1 ? 0 : static_cast<const FrontArgs<float> *>(args)->lean;
+    return precision == 1 ? front_dispatch<double>(0, log2nc, pplog, tl, 0, args, numBlocks, ldsBytes, st)
+                          : front_dispatch<float>(0, log2nc, pplog, tl, mode, args, numBlocks, ldsBytes, st);
 }
 
 // Workgroups of the static-feature kernel that the runtime says fit one CU (0 = unknown).
-int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, bool lean, size_t ldsBytes)
+int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, int mode, size_t ldsBytes)
 {
-    const int n = precision == 1 ? front_dispatch<double>(1, log2nc, pplog, tabLds, false, nullptr, 0, ldsBytes, nullptr)
-                                 : front_dispatch<float>(1, log2nc, pplog, tabLds, lean, nullptr, 0, ldsBytes, nullptr);
+    const int n = precision == 1 ? front_dispatch<double>(1, log2nc, pplog, tabLds, 0, nullptr, 0, ldsBytes, nullptr)
+                                 : front_dispatch<float>(1, log2nc, pplog, tabLds, mode, nullptr, 0, ldsBytes, nullptr);
     return n < 0 ? 0 : n;
 }
 
