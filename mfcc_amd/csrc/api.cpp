@@ -318,8 +318,7 @@ static int choose_tile(MFCCPlan *p)
         }
     }
     // Matrix-core mel filterbank (kernel mode 2): 16 blocks of 4 lanes, each with 4 consecutive
-    // channels ("quad") and a contiguous run of the bins that touch them; the 16 - quads spare
-    // blocks halve the longest runs.  Possible when a frame fills at most a quarter wave
+    // channels ("quad") and a contiguous run of the bins that touch them.  Possible when a frame fills at most a quarter wave
     // (256..1024 complex points at 16 points per lane) and every run fits kMelSteps.
     p->melSteps = 0;
     if (leanCand && pplog == 4 && log2nc >= 8 && log2nc <= 10 && !getenv("MFCC_NO_MELM")) {
@@ -331,28 +330,34 @@ static int choose_tile(MFCCPlan *p)
             if (se[ch] == 0) sb[ch] = k;
             se[ch] = k + 1;
         }
-        struct Piece { int quad, k0, k1, second; };
-        std::vector<Piece> pieces;
-        for (int q = 0; q < NQ && NQ <= 16; ++q) {
-            int k0 = nc, k1 = 0; // bins of segments 4q .. 4q+4: they reach channels 4q .. 4q+3
+        // Runs: quad q's bins are those of segments 4q .. 4q+4 (they reach channels 4q .. 4q+3).
+        // A run may be cut into up to 4 equal parts on neighbouring blocks; the smallest part
+        // length that needs at most 16 blocks wins.
+        struct Piece { int quad, k0, k1, pos, len; }; // pos / len: place in its quad's chain of blocks
+        std::vector<int> q0(NQ, 0), q1(NQ, 0);
+        for (int q = 0; q < NQ; ++q) {
+            int k0 = nc, k1 = 0;
             for (int sIdx = 4 * q; sIdx <= std::min(4 * q + 4, P); ++sIdx)
                 if (se[sIdx] > sb[sIdx]) k0 = std::min(k0, sb[sIdx]), k1 = std::max(k1, se[sIdx]);
             if (k1 < k0) k0 = k1 = 0;
-            pieces.push_back({q, k0, k1, 0});
+            q0[q] = k0, q1[q] = k1;
         }
-        std::vector<char> split(NQ, 0);
-        for (int spare = 16 - NQ; spare > 0 && NQ <= 16; --spare) {
-            int best = -1;
-            for (size_t i = 0; i < pieces.size(); ++i)
-                if (!split[pieces[i].quad] && pieces[i].k1 - pieces[i].k0 > 1 &&
-                    (best < 0 || pieces[i].k1 - pieces[i].k0 > pieces[best].k1 - pieces[best].k0))
-                    best = (int)i;
-            if (best < 0) break;
-            const Piece whole = pieces[best];
-            const int mid = whole.k0 + (whole.k1 - whole.k0 + 1) / 2;
-            split[whole.quad] = 1;
-            pieces[best] = {whole.quad, whole.k0, mid, 0};
-            pieces.insert(pieces.begin() + best + 1, {whole.quad, mid, whole.k1, 1});
+        int part = 0;
+        for (int cand = 1; cand <= nc && !part && NQ <= 16; ++cand) {
+            int blocks = 0;
+            bool ok = true;
+            for (int q = 0; q < NQ; ++q) {
+                const int n = std::max(1, (q1[q] - q0[q] + cand - 1) / cand);
+                ok = ok && n <= 4;
+                blocks += n;
+            }
+            if (ok && blocks <= 16) part = cand;
+        }
+        std::vector<Piece> pieces;
+        for (int q = 0; q < NQ && part; ++q) {
+            const int len = q1[q] - q0[q], n = std::max(1, (len + part - 1) / part);
+            for (int i = 0; i < n; ++i) // equal parts, the first ones one bin longer
+                pieces.push_back({q, q0[q] + (int)((long)len * i / n), q0[q] + (int)((long)len * (i + 1) / n), i, n});
         }
         // Every block reads `steps` consecutive bins from r0 <= k0 (r0 + steps >= k1, inside the
         // frame).  The 32 lanes of a half wave (8 blocks x 4 frame slots, slots 8 banks apart)
@@ -362,7 +367,7 @@ static int choose_tile(MFCCPlan *p)
         for (const Piece &pc : pieces) longest = std::max(longest, pc.k1 - pc.k0);
         std::vector<int> r0(pieces.size(), 0);
         int steps = 0;
-        for (int trial = std::max(longest, 1); trial <= std::min(kMelSteps, nc) && NQ <= 16 && !steps; ++trial) {
+        for (int trial = std::max(longest, 1); trial <= std::min(kMelSteps, nc) && part && !steps; ++trial) {
             std::vector<size_t> order(pieces.size());
             for (size_t i = 0; i < order.size(); ++i) order[i] = i;
             auto choices = [&](size_t b) {
@@ -392,11 +397,11 @@ static int choose_tile(MFCCPlan *p)
             for (int ln = 0; ln < 64; ++ln) p->melMeta[4 * ln + 2] = -1;
             for (size_t b = 0; b < pieces.size(); ++b) {
                 const Piece &pc = pieces[b];
-                const bool owner = pc.second || !split[pc.quad];
+                const bool owner = pc.pos == pc.len - 1;
                 for (int j = 0; j < 4; ++j) {
                     const int ln = 4 * (int)b + j, ch = 4 * pc.quad + j;
                     p->melMeta[4 * ln + 0] = r0[b];
-                    p->melMeta[4 * ln + 1] = (pc.second ? 1 : 0) | (owner ? 2 : 0);
+                    p->melMeta[4 * ln + 1] = (pc.pos >= 1 ? 1 : 0) | (owner ? 2 : 0) | (pc.pos >= 2 ? 4 : 0);
                     p->melMeta[4 * ln + 2] = (owner && ch < P) ? ch : -1;
                     if (ch >= P) continue;
                     for (int t = 0; t < steps; ++t) {

@@ -9,7 +9,7 @@ constexpr int kBlock = 256;       // threads per workgroup of every kernel (4 wa
 constexpr int kMaxLog2Nc = 13;    // fftN <= 16384
 constexpr int kStatRows = 1024;   // rows per workgroup of the z-norm statistics kernels
 constexpr int kRegRows = 64;      // rows per workgroup pass of the regression kernel
-constexpr int kMelSteps = 44;     // most bins one block of the matrix-core mel filterbank walks
+constexpr int kMelSteps = 36;     // most bins one block of the matrix-core mel filterbank walks
 
 // One utterance (or one rank's shard of a long recording) as the kernels see it.
 struct UttDesc {
@@ -48,7 +48,7 @@ struct FrontArgs {
     int lean;                 // kernel mode: 0 general, 1 lean, 2 lean with the matrix-core mel filterbank
     const float *melW;        // mode 2: melSteps x 64 weights, [step][lane]
     const int32_t *melMeta;   // mode 2: 64 x {first bin of the lane's block, flags (1: add the block
-                              // before, 2: writes results), channel or -1, 0}
+                              // before, 4: then the block two before, 2: writes results), channel or -1, 0}
     int melSteps;
     T *out;
     int numTiles;

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     // The 64 lanes form 16 blocks of 4; block b owns 4 consecutive channels and a contiguous bin
     // range.  Per step t lane (b, i) feeds the power of frame slot i at bin r0_b + t and the weight
     // of that bin for channel 4 q_b + i; element r of the result is frame slot r's sum for the
-    // lane's channel.  Wide channel groups are cut over two neighbouring blocks, added at the end.
+    // lane's channel.  Wide channel groups are cut over up to 4 neighbouring blocks, added at the end.
     // The lane's weights stay in registers; r0, the role flags and the channel come from melMeta.
     float melW[MELM ? kMelSteps : 1];
     const T *melA = zbuf;
@@ -963,10 +963,17 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 #pragma unroll
                 for (int t = 0; t < kMelSteps; ++t)
                     macc = __builtin_amdgcn_mfma_f32_4x4x1f32(slotLive ? av[t] : 0.0f, melW[t], macc, 0, 0, 0);
+                // a channel quad cut over up to 4 neighbouring blocks: add the block before, then
+                // the (already doubled) block two before; the chain's last block holds the sum
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { // second block of a pair adds the first block's part
+                for (int r = 0; r < 4; ++r) {
                     const float other = __shfl_up(macc[r], 4, 64);
                     macc[r] += (melFlags & 1) ? other : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float other = __shfl_up(macc[r], 8, 64);
+                    macc[r] += (melFlags & 4) ? other : 0.0f;
                 }
                 if ((melFlags & 2) && melCh >= 0) { // owner of channel melCh: log(max(., 1)), mfcc.c:171-176
 #pragma unroll
