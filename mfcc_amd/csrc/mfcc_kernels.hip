@@ -565,6 +565,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     T *featBase = zbuf + a.rawOrZElems;             // framesPerTile x vSize static features (+ VEC)
     T *fbkSep = featBase + a.featElems;             // framesPerTile x V x P log-mel values (cepstral mode)
     T *red = fbkSep + a.fbkElems;                   // 8 elements for cross-wave sums
+    unsigned *warm = reinterpret_cast<unsigned *>(red + 8) + (tid & (TEAM - 1) & ~63); // prefetch sink, 4 B per lane
     unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
 
     const int bpi = F_channels * F_bps;
@@ -643,19 +644,25 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 
     STAMP_DECL
     STAMP_START;
-    for (int tile = blockIdx.x * NTEAMS + team; tile < a.numTiles; tile += gridDim.x * NTEAMS) {
-        const TileDesc td = a.tiles[tile];
+    const int tstride = gridDim.x * NTEAMS;
+    int tile = blockIdx.x * NTEAMS + team;
+    TileDesc td = {0, 0};
+    if (tile < a.numTiles) td = a.tiles[tile];
+    for (; tile < a.numTiles; tile += tstride) {
         const int nf = (int)((td.src >> 48) & 0xfffu);
         const int lead = (int)((td.src >> 60) & 1u);            // the first sample has a predecessor
         const unsigned char *g0 = a.pcm + (td.src & kTileOffMask);
         const int ns = (nf - 1) * a.inc + a.wlen;                 // frame samples in the tile
+        const long long outRow = td.outRow;
+        const int tnext = tile + tstride;
+        if (tnext < a.numTiles) td = a.tiles[tnext];              // descriptor of the team's next tile
         double mean[4] = {0, 0, 0, 0};
         if (F_zeroMean) {
             const double *m = a.utts[a.tileUtt[tile]].mean;
             mean[0] = m[0], mean[1] = m[1], mean[2] = m[2], mean[3] = m[3];
         }
         // Staging area shifted so that it is 16-byte aligned exactly where the output is.
-        T *dst = a.out + td.outRow * a.step;
+        T *dst = a.out + outRow * a.step;
         const int mis = a.step == a.vSize ? (int)((reinterpret_cast<unsigned long long>(dst) / sizeof(T)) & (VEC - 1)) : 0;
         T *feat = featBase + mis;
 
@@ -715,6 +722,20 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             for (int v = 0; v < F_V; ++v) rows[v * a.rowPitch + ns + s] = (T)0;
         team_sync<TEAM>();
         STAMP(1);
+
+        // Pull the next tile's cache lines towards L2 while this tile is computed: one 4-byte
+        // direct-to-LDS load per 128-byte line into a scratch word per lane (no register result,
+        // so nothing waits for it); the data itself is loaded when that tile starts.
+        if (tnext < a.numTiles && !SKIP(7)) {
+            const int nfn = (int)((td.src >> 48) & 0xfffu);
+            const int nbn = ((nfn - 1) * a.inc + a.wlen + 1) * bpi;
+            const unsigned char *gn = a.pcm + (td.src & kTileOffMask);
+            for (int i = tt; i * 128 < nbn; i += TEAM)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) unsigned *)(
+                        reinterpret_cast<unsigned long long>(gn + i * 128) & ~3ull),
+                    (__attribute__((address_space(3))) unsigned *)warm, 4, 0, 0);
+        }
 
         const int nItems = nf * F_V;
         for (int base = 0; base < nItems; base += GT) {
