@@ -1111,9 +1111,10 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             for (int i = tt; i < nv; i += TEAM) dv[i] = fv[i];
             for (int i = head + nv * VEC + tt; i < n; i += TEAM) dst[i] = feat[i];
         } else {
-            for (int r = tt >> 6; r < (SKIP(8) ? 0 : nf); r += TEAM / 64) {
-                T *drow = dst + (long long)r * a.step;
-                for (int c = tt & 63; c < a.vSize; c += 64) drow[c] = feat[r * a.vSize + c];
+            // delta slots follow every row's static block: one element per lane, rows back to back
+            for (int i = tt; i < (SKIP(8) ? 0 : nf * a.vSize); i += TEAM) {
+                const int r = i / a.vSize, c = i - r * a.vSize;
+                dst[(long long)r * a.step + c] = feat[i];
             }
         }
         STAMP(9);
