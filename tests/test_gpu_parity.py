@@ -91,6 +91,29 @@ def test_every_fft_size(oracle, wlen):
         _compare(got, ref, kw, f64)
 
 
+@pytest.mark.parametrize("wlen,bank", [(8, 2), (50, 7), (100, 12), (200, 23), (256, 20), (400, 5), (400, 13),
+                                       (400, 23), (400, 40), (400, 64), (400, 80), (512, 26), (800, 40),
+                                       (1024, 33), (1600, 40), (2048, 64), (3000, 40), (5000, 24)])
+@pytest.mark.parametrize("cepstral", [False, True])
+def test_lean_kernel_modes(oracle, wlen, bank, cepstral):
+    """Mono 16-bit single-row configurations without the per-frame extras take the lean kernel, and
+    from 512- to 2048-point frames its matrix-core mel filterbank: every channel count layout
+    (quads cut over 1..4 blocks, more than 16 quads falling back), even frame shifts, tiles that
+    end on a partial round, log-mel and cepstral outputs."""
+    inc = max(2, (wlen // 5) & ~1)
+    kw = dict(sampleRate=16000, lowpassfre=-1, hipassfre=-1, preemphasise=0.97, wlen=wlen, inc=inc,
+              vecNum=1, fbankFlag=0 if cepstral else 1, bankNum=bank, MFCCNum=min(bank, 13),
+              MFCC0thFlag=1 if cepstral else 0, energyFlag=1 if cepstral else 0)
+    n = wlen + 36 * inc + 1  # 37 frames: several tiles, the last one ragged
+    # noise only: with a strong tone the weakest bins sit at the single-precision FFT's noise floor
+    # (1e-7 of the peak), which channels of one or two bins would show as > 1e-4 in the logarithm
+    pcm = _pcm(n, 1, 2, wlen + bank, 16000, tone=0)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
+    assert ref.shape[0] == 37
+    got = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], 1, 2)[0]
+    _compare(got, ref, kw, False)
+
+
 def test_ragged_batch_and_edge_lengths(oracle):
     """Empty, shorter than a window, exactly one window, one sample short of two frames, long."""
     kw = CONFIGS["c3"]
