@@ -9,7 +9,7 @@ constexpr int kBlock = 256;       // threads per workgroup of every kernel (4 wa
 constexpr int kMaxLog2Nc = 13;    // fftN <= 16384
 constexpr int kStatRows = 1024;   // rows per workgroup of the z-norm statistics kernels
 constexpr int kRegRows = 64;      // rows per workgroup pass of the regression kernel
-constexpr int kMelSteps = 36;     // most bins one block of the matrix-core mel filterbank walks
+constexpr int kMelSteps = 32;     // most bins one block of the matrix-core mel filterbank walks
 
 // One utterance (or one rank's shard of a long recording) as the kernels see it.
 struct UttDesc {

@@ -644,6 +644,18 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 
     STAMP_DECL
     STAMP_START;
+    // MELM: the next tile's raw bytes are fetched into registers during the last round's mel phase
+    // (the FFT's point registers are free then) and parked in LDS when that tile starts: up to PFN
+    // 16-byte vectors per lane plus one byte of the last partial vector; longer tiles load the rest
+    // when they start.
+    typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
+    constexpr int PFN = MELM ? 3 : 1;
+    u4u pf[PFN];
+    unsigned pfTail = 0;
+    bool pfValid = false; // team-uniform
+#pragma unroll
+    for (int j = 0; j < PFN; ++j) pf[j] = u4u{0u, 0u, 0u, 0u};
+
     const int tstride = gridDim.x * NTEAMS;
     int tile = blockIdx.x * NTEAMS + team;
     TileDesc td = {0, 0};
@@ -673,9 +685,20 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             // Copy starts exactly at the predecessor of the tile's first sample (16-byte vector
             // loads from a possibly unaligned address), the last partial vector byte by byte so
             // that nothing behind the tile's bytes is touched.
-            typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
             const int nbytes = (ns + 1) * bpi, nfull = nbytes >> 4;
-            if (!SKIP(7)) {
+            if (MELM && pfValid && !SKIP(7)) {
+#pragma unroll
+                for (int j = 0; j < PFN; ++j) {
+                    const int i = tt + j * TEAM;
+                    if (i < nfull) reinterpret_cast<uint4 *>(raw)[i] = make_uint4(pf[j].x, pf[j].y, pf[j].z, pf[j].w);
+                }
+                for (int i = tt + PFN * TEAM; i < nfull; i += TEAM) {
+                    const u4u vv4 = reinterpret_cast<const u4u *>(g0)[i];
+                    reinterpret_cast<uint4 *>(raw)[i] = make_uint4(vv4.x, vv4.y, vv4.z, vv4.w);
+                }
+                if (tt < nbytes - (nfull << 4))
+                    reinterpret_cast<unsigned char *>(raw)[(nfull << 4) + tt] = (unsigned char)pfTail;
+            } else if (!SKIP(7)) {
                 for (int i = tt; i < nfull; i += 2 * TEAM) { // two loads in flight per lane
                     const bool second = i + TEAM < nfull;
                     const u4u va = reinterpret_cast<const u4u *>(g0)[i];
@@ -963,6 +986,20 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             }
 
             if constexpr (MELM) {
+                if (base + GT >= nItems) { // last round of the tile: start the next tile's loads
+                    pfValid = tnext < a.numTiles && ((td.src >> 60) & 1u) != 0 && !SKIP(7);
+                    if (pfValid) {
+                        const int nfn = (int)((td.src >> 48) & 0xfffu);
+                        const int nbn = ((nfn - 1) * a.inc + a.wlen + 1) * bpi, nfulln = nbn >> 4;
+                        const unsigned char *gn = a.pcm + (td.src & kTileOffMask);
+#pragma unroll
+                        for (int j = 0; j < PFN; ++j) {
+                            const int i = tt + j * TEAM;
+                            if (i < nfulln) pf[j] = reinterpret_cast<const u4u *>(gn)[i];
+                        }
+                        if (tt < nbn - (nfulln << 4)) pfTail = gn[(nfulln << 4) + tt];
+                    }
+                }
                 // plain power values of the frame into its work area, bin order
 #pragma unroll
                 for (int q = 0; q < NPAIR; ++q) {
