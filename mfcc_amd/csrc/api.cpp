@@ -48,6 +48,9 @@ struct MFCCPlan {
     int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0, teamElems = 0, numRegBlocks = 0;
     int tabElems = 0, winPad = 0, featElems = 0, fbkElems = 0, rowTail = 0;
     int blocksPerCu = 1, numCus = 256, pplog = 4;
+    int deltaSubRows = 0, deltaRedOffset = 0; // fused delta kernel geometry (0: not used)
+    size_t deltaLds = 0;
+    double *dBlockPartial = nullptr;
     int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
     std::vector<float> melW;
     std::vector<int32_t> melMeta;
@@ -581,6 +584,23 @@ static int finish_plan(MFCCPlan *p)
         HIP_TRY(hipMalloc((void **)&p->dMelMeta, p->melMeta.size() * sizeof(int32_t)));
         HIP_TRY(hipMemcpy(p->dMelMeta, p->melMeta.data(), p->melMeta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    // Fused delta (+ statistics) pass: orders 2 and 3, rows of at most one workgroup of columns,
+    // two LDS tiles of (subRows + 2 halo) rows within 64 KiB.
+    p->deltaSubRows = 0;
+    if ((c->cfg.regreOrder == 2 || c->cfg.regreOrder == 3) && c->vSize <= kBlock && !getenv("MFCC_NO_FUSED_DELTA")) {
+        const size_t elb = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
+        const int halo = (c->cfg.regreOrder - 1) * c->cfg.delwin;
+        for (int sr = 256; sr >= 8 && !p->deltaSubRows; sr /= 2) {
+            const size_t tiles = (2 * (size_t)(sr + 2 * halo) * c->vSize * elb + 15) & ~(size_t)15;
+            if (tiles + 2 * kBlock * sizeof(double) <= 64 * 1024 && sr >= c->cfg.delwin) {
+                p->deltaSubRows = sr;
+                p->deltaRedOffset = (int)tiles;
+                p->deltaLds = tiles + 2 * kBlock * sizeof(double);
+            }
+        }
+    }
+    if (p->deltaSubRows && c->cfg.znormFlag && !p->shard)
+        HIP_TRY(hipMalloc((void **)&p->dBlockPartial, std::max<size_t>(regUtt.size(), 1) * 2 * c->step * sizeof(double)));
     const bool needStats = c->cfg.znormFlag != 0;
     if (needStats) {
         HIP_TRY(hipMalloc((void **)&p->dChunkUtt, std::max<size_t>(chunkUtt.size(), 1) * sizeof(int32_t)));
@@ -717,6 +737,7 @@ extern "C" void MFCCPlanDestroy(MFCCPlan *p)
     (void)hipFree(p->dTiles);
     (void)hipFree(p->dRegUtt);
     (void)hipFree(p->dMelW);
+    (void)hipFree(p->dBlockPartial);
     (void)hipFree(p->dMelMeta);
     (void)hipFree(p->dChunkUtt);
     (void)hipFree(p->dLaneSeg);
@@ -881,6 +902,30 @@ static int run_regress(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
     return MFCC_OK;
 }
 
+// All regression orders in one pass (and the z-norm partial sums of batch plans).
+template <typename T>
+static int run_delta(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
+{
+    double sigmaT2 = 0.0;
+    for (int t = 1; t <= c->cfg.delwin; ++t) sigmaT2 += (double)t * t;
+    DeltaArgs<T> a;
+    memset(&a, 0, sizeof a);
+    a.data = static_cast<T *>(outDev);
+    a.utts = p->dUtts;
+    a.blockUtt = p->dRegUtt;
+    a.numBlocks = p->numRegBlocks;
+    a.vSize = c->vSize;
+    a.step = c->step;
+    a.delwin = c->cfg.delwin;
+    a.subRows = p->deltaSubRows;
+    a.redOffset = p->deltaRedOffset;
+    a.sigmaT2 = 2.0 * sigmaT2;
+    a.partial = p->dBlockPartial;
+    const int rc = launch_delta(c->cfg.precision, &a, c->cfg.regreOrder, p->deltaLds, stream);
+    if (rc) return set_error("delta kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
 template <typename T>
 static StatArgs<T> stat_args(MFCCContext *c, MFCCPlan *p, void *outDev)
 {
@@ -952,12 +997,18 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
         HIP_TRY(hipEventRecord(p->evStop, st));
         p->timed = true;
     }
-    rc = f64 ? run_regress<double>(c, p, outDev, stream) : run_regress<float>(c, p, outDev, stream);
+    const bool fused = p->deltaSubRows > 0;
+    if (fused)
+        rc = f64 ? run_delta<double>(c, p, outDev, stream) : run_delta<float>(c, p, outDev, stream);
+    else
+        rc = f64 ? run_regress<double>(c, p, outDev, stream) : run_regress<float>(c, p, outDev, stream);
     if (rc) return rc;
     if (c->cfg.znormFlag && !p->shard) {
-        if ((rc = run_colstats(c, p, outDev, stream))) return rc;
+        const bool byBlock = fused && p->dBlockPartial;
+        if (!byBlock && (rc = run_colstats(c, p, outDev, stream))) return rc;
         StatArgs<float> fa = stat_args<float>(c, p, nullptr);
-        const int e = launch_colfinal(fa, p->numUtts, stream);
+        if (byBlock) fa.partial = p->dBlockPartial;
+        const int e = launch_colfinal(fa, p->numUtts, byBlock, stream);
         if (e) return set_error("z-norm finalise kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
         if ((rc = run_normalize(c, p, outDev, false, nullptr, stream))) return rc;
     }
@@ -978,7 +1029,7 @@ extern "C" int MFCCShardColumnSums(MFCCContext *c, MFCCPlan *p, const void *outD
     int rc = run_colstats(c, p, const_cast<void *>(outDev), stream);
     if (rc) return rc;
     StatArgs<float> fa = stat_args<float>(c, p, nullptr);
-    const int e = launch_shardfinal(fa, p->numChunks, sumsDev, stream);
+    const int e = launch_shardfinal(fa, p->numChunks, false, sumsDev, stream);
     if (e) return set_error("shard statistics kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
     return MFCC_OK;
 }

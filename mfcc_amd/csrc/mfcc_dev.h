@@ -8,7 +8,7 @@ namespace mfcc {
 constexpr int kBlock = 256;       // threads per workgroup of every kernel (4 waves of 64)
 constexpr int kMaxLog2Nc = 13;    // fftN <= 16384
 constexpr int kStatRows = 1024;   // rows per workgroup of the z-norm statistics kernels
-constexpr int kRegRows = 64;      // rows per workgroup pass of the regression kernel
+constexpr int kRegRows = 1024;    // rows per workgroup of the regression / fused delta kernels
 constexpr int kMelSteps = 32;     // most bins one block of the matrix-core mel filterbank walks
 
 // One utterance (or one rank's shard of a long recording) as the kernels see it.
@@ -92,6 +92,20 @@ struct RegressArgs {
     double sigmaT2;
 };
 
+// Fused delta kernel: all regression orders of a block of rows, plus its column sums when partial != 0.
+template <typename T>
+struct DeltaArgs {
+    T *data;
+    const UttDesc *utts;
+    const int32_t *blockUtt; // utterance of each kRegRows-row block
+    int numBlocks;
+    int vSize, step, delwin;
+    int subRows;             // rows per LDS sub-tile
+    int redOffset;           // byte offset of the 2 * kBlock doubles of reduction scratch in LDS
+    double sigmaT2;
+    double *partial;         // numBlocks x 2*step: per-block column sums and sums of squares, or NULL
+};
+
 template <typename T>
 struct StatArgs {
     T *data;
@@ -113,8 +127,9 @@ int front_waves_limit(int precision, int log2nc, int pplog); // waves per SIMD t
 int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, int mode, size_t ldsBytes);
 int launch_regress(int precision, const void *args, int numBlocks, void *stream);
 int launch_colstats(int precision, const void *args, int numChunks, void *stream);
-int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream);
-int launch_shardfinal(const StatArgs<float> &a, int numChunks, double *sumsOut, void *stream);
+int launch_colfinal(const StatArgs<float> &a, int numUtts, bool byBlock, void *stream);
+int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, double *sumsOut, void *stream);
+int launch_delta(int precision, const void *args, int orders, size_t ldsBytes, void *stream); // -2: no such variant
 int launch_normalize(int precision, const void *args, int numChunks, bool shardSums,
                      const double *sums, void *stream);
 int launch_chansums(const unsigned char *pcm, int channels, int bps, int64_t firstByte,

@@ -1190,6 +1190,111 @@ __global__ __launch_bounds__(kBlock) void k_regress(const RegressArgs<T> a)
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused deltas: every regression order of one block of rows in one pass, plus (optionally) the
+// block's column sums for the z-norm.  The static rows of a sub-tile and a halo of
+// (ORD - 1) * delwin rows per side are loaded once into LDS (row indices clamped to the utterance,
+// as Regress clamps them); each order is computed from the previous one inside LDS, where the
+// entry for a row outside the utterance is the value at the clamped row.  Arithmetic and
+// rounding are those of k_regress.  Statistics cover the rows in [ownBegin, ownBegin + ownCount).
+// ------------------------------------------------------------------------------------------
+
+template <typename T, int ORD>
+__global__ __launch_bounds__(kBlock) void k_delta(const DeltaArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    const int H = (ORD - 1) * a.delwin, SR = a.subRows, W = a.vSize;
+    T *bufA = reinterpret_cast<T *>(dsm), *bufB = bufA + (size_t)(SR + 2 * H) * W;
+    double *red = reinterpret_cast<double *>(dsm + a.redOffset); // 2 * kBlock doubles
+    const int blk = blockIdx.x;
+    const int u = a.blockUtt[blk];
+    const UttDesc ud = a.utts[u];
+    const int n = ud.numFrames;
+    const int r0 = (blk - ud.regBegin) * kRegRows;
+    const int nr = min(kRegRows, n - r0);
+    T *base = a.data + ud.outRow * a.step;
+    const int tid = threadIdx.x;
+    // statistics: lane (rl, col) sums rows rl, rl + rowLanes, ... of every sub-tile
+    double s1[ORD], s2[ORD];
+#pragma unroll
+    for (int o = 0; o < ORD; ++o) s1[o] = s2[o] = 0;
+    const bool stats = a.partial != nullptr;
+    const int ncol = min(kBlock, W), rowLanes = kBlock / ncol;
+    const int col = tid % ncol, rl = tid / ncol;
+
+    for (int s = r0; s < r0 + nr; s += SR) {
+        const int rows = min(SR, r0 + nr - s);
+        // static rows s - H .. s + rows + H - 1, clamped
+        for (int i = tid; i < (rows + 2 * H) * W; i += kBlock) {
+            const int p = i / W, c = i - p * W;
+            const int t = min(max(s - H + p, 0), n - 1);
+            bufA[i] = base[(long long)t * a.step + c];
+        }
+        __syncthreads();
+        if (stats && rl < rowLanes)
+            for (int r = rl; r < rows; r += rowLanes) {
+                const int row = s + r;
+                if (row >= ud.ownBegin && row < ud.ownBegin + ud.ownCount) {
+                    const double x = (double)bufA[(r + H) * W + col];
+                    s1[0] += x;
+                    s2[0] += x * x;
+                }
+            }
+        T *prev = bufA, *next = bufB;
+        int hp = H; // halo of `prev`: its entry p is row s - hp + p
+#pragma unroll
+        for (int o = 1; o < ORD; ++o) {
+            const int hn = hp - a.delwin;
+            for (int i = tid; i < (rows + 2 * hn) * W; i += kBlock) {
+                const int p = i / W, c = i - p * W;
+                const int t = min(max(s - hn + p, 0), n - 1); // the row whose delta this entry holds
+                const int q = t - (s - hp);                    // its entry in prev
+                T sum = 0;
+                for (int tau = 1; tau <= a.delwin; ++tau)
+                    sum += (T)tau * (prev[(q + tau) * W + c] - prev[(q - tau) * W + c]);
+                const T d = (T)((double)sum / a.sigmaT2);
+                next[i] = d;
+                const int row = s - hn + p;
+                if (row >= s && row < s + rows) base[(long long)row * a.step + o * W + c] = d;
+            }
+            __syncthreads();
+            T *tmp = prev;
+            prev = next;
+            next = tmp;
+            hp = hn;
+            if (stats && rl < rowLanes)
+                for (int r = rl; r < rows; r += rowLanes) {
+                    const int row = s + r;
+                    if (row >= ud.ownBegin && row < ud.ownBegin + ud.ownCount) {
+                        const double x = (double)prev[(r + hp) * W + col];
+                        s1[o] += x;
+                        s2[o] += x * x;
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    if (stats) {
+        double *out = a.partial + (long long)blk * 2 * a.step;
+#pragma unroll
+        for (int o = 0; o < ORD; ++o) {
+            red[tid] = s1[o];
+            red[kBlock + tid] = s2[o];
+            __syncthreads();
+            if (tid < ncol) {
+                double t1 = 0, t2 = 0;
+                for (int q = 0; q < rowLanes; ++q) {
+                    t1 += red[q * ncol + tid];
+                    t2 += red[kBlock + q * ncol + tid];
+                }
+                out[o * W + tid] = t1;
+                out[a.step + o * W + tid] = t2;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // z-norm: per-chunk column sums (double), per-utterance finalise, normalise
 // ------------------------------------------------------------------------------------------
 
@@ -1232,12 +1337,17 @@ __global__ __launch_bounds__(kBlock) void k_colstats(const StatArgs<T> a)
 }
 
 // One workgroup per utterance: chunk partials summed in chunk order -> mean and 1/std.
+// byBlock: the partials are per regression block (k_delta) instead of per statistics chunk.
 __global__ __launch_bounds__(kBlock) void k_colfinal(const UttDesc *utts, const double *partial,
-                                                     double *stats, int step)
+                                                     double *stats, int step, int byBlock)
 {
     const int u = blockIdx.x;
-    const UttDesc ud = utts[u];
-    const int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
+    UttDesc ud = utts[u];
+    int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
+    if (byBlock) {
+        nchunk = (ud.numFrames + kRegRows - 1) / kRegRows;
+        ud.statBegin = ud.regBegin;
+    }
     for (int c = threadIdx.x; c < step; c += kBlock) {
         double s = 0, s2 = 0;
         for (int q = 0; q < nchunk; ++q) {
@@ -1255,10 +1365,14 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(const UttDesc *utts, const 
 
 // Shard plans: one utterance; raw sums out (sum x, sum x^2 per column, then the row count).
 __global__ __launch_bounds__(kBlock) void k_shardfinal(const UttDesc *utts, const double *partial,
-                                                       double *sums, int step)
+                                                       double *sums, int step, int byBlock)
 {
-    const UttDesc ud = utts[0];
-    const int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
+    UttDesc ud = utts[0];
+    int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
+    if (byBlock) {
+        nchunk = (ud.numFrames + kRegRows - 1) / kRegRows;
+        ud.statBegin = ud.regBegin;
+    }
     for (int c = threadIdx.x; c < 2 * step; c += kBlock) {
         double s = 0;
         for (int q = 0; q < nchunk; ++q) s += partial[(long long)(ud.statBegin + q) * 2 * step + c];
@@ -1544,20 +1658,50 @@ int launch_colstats(int precision, const void *args, int numChunks, void *stream
     return (int)hipGetLastError();
 }
 
-int launch_colfinal(const StatArgs<float> &a, int numUtts, void *stream)
+int launch_colfinal(const StatArgs<float> &a, int numUtts, bool byBlock, void *stream)
 {
     if (numUtts <= 0) return 0;
     hipLaunchKernelGGL(k_colfinal, dim3(numUtts), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       a.utts, a.partial, a.stats, a.step);
+                       a.utts, a.partial, a.stats, a.step, byBlock ? 1 : 0);
     return (int)hipGetLastError();
 }
 
-int launch_shardfinal(const StatArgs<float> &a, int numChunks, double *sumsOut, void *stream)
+int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, double *sumsOut, void *stream)
 {
     (void)numChunks;
     hipLaunchKernelGGL(k_shardfinal, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       a.utts, a.partial, sumsOut, a.step);
+                       a.utts, a.partial, sumsOut, a.step, byBlock ? 1 : 0);
     return (int)hipGetLastError();
+}
+
+// Fused delta (+ statistics) pass; returns -2 when this order count has no instantiation.
+template <typename T, int ORD>
+static int launch_delta_o(const DeltaArgs<T> &a, size_t lds, hipStream_t st)
+{
+    static bool attrSet[16] = {};
+    int dev = 0;
+    MFCC_HIP_OK(hipGetDevice(&dev));
+    if (dev < 16 && !attrSet[dev]) {
+        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta<T, ORD>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attrSet[dev] = true;
+    }
+    hipLaunchKernelGGL((k_delta<T, ORD>), dim3(a.numBlocks), dim3(kBlock), lds, st, a);
+    return (int)hipGetLastError();
+}
+template <typename T>
+static int launch_delta_t(const DeltaArgs<T> &a, int orders, size_t lds, hipStream_t st)
+{
+    if (a.numBlocks <= 0) return 0;
+    if (orders == 2) return launch_delta_o<T, 2>(a, lds, st);
+    if (orders == 3) return launch_delta_o<T, 3>(a, lds, st);
+    return -2;
+}
+int launch_delta(int precision, const void *args, int orders, size_t ldsBytes, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return precision == 1 ? launch_delta_t<double>(*static_cast<const DeltaArgs<double> *>(args), orders, ldsBytes, st)
+                          : launch_delta_t<float>(*static_cast<const DeltaArgs<float> *>(args), orders, ldsBytes, st);
 }
 
 int launch_normalize(int precision, const void *args, int numChunks, bool shardSums,
