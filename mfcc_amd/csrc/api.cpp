@@ -529,6 +529,9 @@ static int finish_plan(MFCCPlan *p)
     tileDesc.reserve((size_t)tiles);
     chunkUtt.reserve((size_t)chunks);
     regUtt.reserve((size_t)regBlocks);
+    int64_t planEnd = 0; // one past the last PCM byte the plan owns
+    for (const UttDesc &d : p->utts)
+        if (d.numFrames > 0) planEnd = std::max<int64_t>(planEnd, d.byteOff + (int64_t)d.numInstants * bpi);
     for (int u = 0; u < p->numUtts; ++u) {
         const UttDesc &d = p->utts[u];
         for (int f0 = 0; f0 < d.numFrames; f0 += p->framesPerTile) {
@@ -539,6 +542,11 @@ static int finish_plan(MFCCPlan *p)
             if (off > kTileOffMask) return set_error("PCM buffer larger than 2^48 bytes"), MFCC_E_ARG;
             TileDesc td;
             td.src = off | ((uint64_t)nf << 48) | ((uint64_t)(first > 0 ? 1 : 0) << 60);
+            if (p->mode == 2 && first > 0) {
+                const int64_t elems = (int64_t)(nf - 1) * c->cfg.inc + c->cfg.wlen + 1; // with the predecessor
+                const int64_t vecs = (elems + 7) / 8;
+                if (vecs <= 3 * 64 && (int64_t)off + vecs * 16 <= planEnd) td.src |= 1ull << 61;
+            }
             td.outRow = d.outRow + f0;
             tileDesc.push_back(td);
             tileUtt.push_back(u);

@@ -32,7 +32,9 @@ struct UttDesc {
 struct TileDesc {
     uint64_t src;   // bits 0..47: byte offset (inside the PCM buffer) of the pre-emphasis predecessor
                     // of the tile's first sample, or of that sample itself when it starts the signal;
-                    // bits 48..59: frames in the tile; bit 60: the predecessor exists
+                    // bits 48..59: frames in the tile; bit 60: the predecessor exists; bit 61: register path
+                    // allowed (kernel mode 2: predecessor exists, at most 3 x 64 vectors of 8 samples, and
+                    // the bytes up to the end of the last vector lie inside the planned PCM extent)
     int64_t outRow; // output row of the tile's first frame
 };
 constexpr uint64_t kTileOffMask = (1ull << 48) - 1;

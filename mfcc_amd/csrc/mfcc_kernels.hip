@@ -644,14 +644,12 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 
     STAMP_DECL
     STAMP_START;
-    // MELM: the next tile's raw bytes are fetched into registers during the last round's mel phase
-    // (the FFT's point registers are free then) and parked in LDS when that tile starts: up to PFN
-    // 16-byte vectors per lane plus one byte of the last partial vector; longer tiles load the rest
-    // when they start.
+    // MELM: the next tile's raw samples are fetched into registers during the last round's mel phase
+    // (the FFT's point registers are free then): PFN 16-byte vectors per lane, for tiles the host
+    // marked as fitting (TileDesc bit 61).
     typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
     constexpr int PFN = MELM ? 3 : 1;
     u4u pf[PFN];
-    unsigned pfTail = 0;
     bool pfValid = false; // team-uniform
 #pragma unroll
     for (int j = 0; j < PFN; ++j) pf[j] = u4u{0u, 0u, 0u, 0u};
@@ -666,6 +664,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         const unsigned char *g0 = a.pcm + (td.src & kTileOffMask);
         const int ns = (nf - 1) * a.inc + a.wlen;                 // frame samples in the tile
         const long long outRow = td.outRow;
+        const bool direct = MELM && ((td.src >> 61) & 1u) != 0; // see the register path below
         const int tnext = tile + tstride;
         if (tnext < a.numTiles) td = a.tiles[tnext];              // descriptor of the team's next tile
         double mean[4] = {0, 0, 0, 0};
@@ -681,24 +680,47 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         // A: tile bytes -> LDS -> derived, mean-free, pre-emphasised rows (see unpack_tile*).
         const bool exact = sizeof(T) == 8 || F_zc != 0;
         const bool fastA = lead && (F_bps == 2 || F_bps == 3);
-        if (fastA) {
+        if (direct) {
+            // Register path (16-bit mono, the tile's samples fit PFN vectors per lane, the bytes up
+            // to the end of its last vector lie inside the PCM buffer): vector j = raw samples
+            // 8j .. 8j+7, sample 0 being the predecessor of the tile's first sample; they arrive
+            // in registers (usually fetched during the previous tile), are pre-emphasised there
+            // -- row[s] = raw[s+1] - k raw[s], the vector's last output taking raw[8j+8] from the
+            // next lane -- and stored as two 16-byte vectors; LDS never sees the raw bytes.
+            const int nvec = (ns + 1 + 7) >> 3;
+            if (!pfValid) {
+#pragma unroll
+                for (int j = 0; j < PFN; ++j)
+                    if (tt + j * TEAM < nvec) pf[j] = reinterpret_cast<const u4u *>(g0)[tt + j * TEAM];
+            }
+            const float kf = (float)a.preK;
+#pragma unroll
+            for (int j = 0; j < PFN; ++j) {
+                const int vj = tt + j * TEAM;
+                unsigned nx = (unsigned)__shfl_down((int)pf[j].x, 1, 64);
+                const unsigned wrap = j + 1 < PFN ? (unsigned)__shfl((int)pf[j + 1 < PFN ? j + 1 : j].x, 0, 64) : 0u;
+                nx = (tt & 63) == 63 ? wrap : nx;
+                if (vj < nvec) {
+                    const unsigned d[5] = {pf[j].x, pf[j].y, pf[j].z, pf[j].w, nx};
+                    float sm[9];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i)
+                        sm[i] = (float)(short)((i & 1) ? (d[i >> 1] >> 16) : (d[i >> 1] & 0xffffu));
+                    float y[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y[i] = 8 * vj + i < ns ? sm[i + 1] - kf * sm[i] : 0.0f;
+                    float *dstRow = reinterpret_cast<float *>(rows) + 8 * vj;
+                    *reinterpret_cast<float4 *>(dstRow) = make_float4(y[0], y[1], y[2], y[3]);
+                    *reinterpret_cast<float4 *>(dstRow + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                }
+            }
+            STAMP(0);
+        } else if (fastA) {
             // Copy starts exactly at the predecessor of the tile's first sample (16-byte vector
             // loads from a possibly unaligned address), the last partial vector byte by byte so
             // that nothing behind the tile's bytes is touched.
             const int nbytes = (ns + 1) * bpi, nfull = nbytes >> 4;
-            if (MELM && pfValid && !SKIP(7)) {
-#pragma unroll
-                for (int j = 0; j < PFN; ++j) {
-                    const int i = tt + j * TEAM;
-                    if (i < nfull) reinterpret_cast<uint4 *>(raw)[i] = make_uint4(pf[j].x, pf[j].y, pf[j].z, pf[j].w);
-                }
-                for (int i = tt + PFN * TEAM; i < nfull; i += TEAM) {
-                    const u4u vv4 = reinterpret_cast<const u4u *>(g0)[i];
-                    reinterpret_cast<uint4 *>(raw)[i] = make_uint4(vv4.x, vv4.y, vv4.z, vv4.w);
-                }
-                if (tt < nbytes - (nfull << 4))
-                    reinterpret_cast<unsigned char *>(raw)[(nfull << 4) + tt] = (unsigned char)pfTail;
-            } else if (!SKIP(7)) {
+            if (!SKIP(7)) {
                 for (int i = tt; i < nfull; i += 2 * TEAM) { // two loads in flight per lane
                     const bool second = i + TEAM < nfull;
                     const u4u va = reinterpret_cast<const u4u *>(g0)[i];
@@ -987,17 +1009,14 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 
             if constexpr (MELM) {
                 if (base + GT >= nItems) { // last round of the tile: start the next tile's loads
-                    pfValid = tnext < a.numTiles && ((td.src >> 60) & 1u) != 0 && !SKIP(7);
+                    pfValid = tnext < a.numTiles && ((td.src >> 61) & 1u) != 0 && !SKIP(7);
                     if (pfValid) {
                         const int nfn = (int)((td.src >> 48) & 0xfffu);
-                        const int nbn = ((nfn - 1) * a.inc + a.wlen + 1) * bpi, nfulln = nbn >> 4;
+                        const int nvn = ((nfn - 1) * a.inc + a.wlen + 1 + 7) >> 3;
                         const unsigned char *gn = a.pcm + (td.src & kTileOffMask);
 #pragma unroll
-                        for (int j = 0; j < PFN; ++j) {
-                            const int i = tt + j * TEAM;
-                            if (i < nfulln) pf[j] = reinterpret_cast<const u4u *>(gn)[i];
-                        }
-                        if (tt < nbn - (nfulln << 4)) pfTail = gn[(nfulln << 4) + tt];
+                        for (int j = 0; j < PFN; ++j)
+                            if (tt + j * TEAM < nvn) pf[j] = reinterpret_cast<const u4u *>(gn)[tt + j * TEAM];
                     }
                 }
                 // plain power values of the frame into its work area, bin order
