@@ -721,13 +721,17 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             // that nothing behind the tile's bytes is touched.
             const int nbytes = (ns + 1) * bpi, nfull = nbytes >> 4;
             if (!SKIP(7)) {
-                for (int i = tt; i < nfull; i += 2 * TEAM) { // two loads in flight per lane
-                    const bool second = i + TEAM < nfull;
-                    const u4u va = reinterpret_cast<const u4u *>(g0)[i];
-                    u4u vb = va;
-                    if (second) vb = reinterpret_cast<const u4u *>(g0)[i + TEAM];
-                    reinterpret_cast<uint4 *>(raw)[i] = make_uint4(va.x, va.y, va.z, va.w);
-                    if (second) reinterpret_cast<uint4 *>(raw)[i + TEAM] = make_uint4(vb.x, vb.y, vb.z, vb.w);
+                for (int i = tt; i < nfull; i += 4 * TEAM) { // four loads in flight per lane
+                    u4u v4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ij = i + j * TEAM < nfull ? i + j * TEAM : i;
+                        v4[j] = reinterpret_cast<const u4u *>(g0)[ij];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (i + j * TEAM < nfull)
+                            reinterpret_cast<uint4 *>(raw)[i + j * TEAM] = make_uint4(v4[j].x, v4[j].y, v4[j].z, v4[j].w);
                 }
                 for (int i = (nfull << 4) + tt; i < nbytes; i += TEAM)
                     reinterpret_cast<unsigned char *>(raw)[i] = g0[i];
@@ -862,11 +866,10 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 for (int i = 0; i < PPL; ++i) {
                     const int s0 = 2 * (l + G * i);
                     const T x0 = x[s0], x1 = x[s0 + 1], x2 = x[s0 + 2];
-                    const T w1 = win[s0 + 1], w2 = win[s0 + 2];
                     const bool c01 = (x0 < 0 && x1 > 0) || (x0 > 0 && x1 < 0);
                     const bool c12 = (x1 < 0 && x2 > 0) || (x1 > 0 && x2 < 0);
-                    zc += (c01 && w1 > 0) ? 1 : 0;
-                    zc += (c12 && w2 > 0) ? 1 : 0;
+                    zc += (c01 && s0 + 1 < a.wlen) ? 1 : 0; // pairs inside the frame only
+                    zc += (c12 && s0 + 2 < a.wlen) ? 1 : 0;
                 }
                 zc = group_sum<int, G>(zc, reinterpret_cast<int *>(red), tt);
             }
