@@ -1134,8 +1134,10 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             // The table's row M is all ones (C0); its rows are zero from k = P to the pitch.
             const int JW = a.M + a.c0Flag;
             const int wv = tt >> 6, i16 = tt & 15, g4 = (tt >> 4) & 3;
-            for (int ib = wv; ib * 16 < nItems; ib += TEAM / 64)
-                for (int jb = 0; jb * 16 < JW; ++jb) {
+            const int njb = (JW + 15) >> 4, nib = (nItems + 15) >> 4;
+            for (int pr = wv; pr < nib * njb; pr += TEAM / 64) { // (item block, coefficient block) per wave
+                const int ib = pr / njb, jb = pr - ib * njb;
+                {
                     const int itemA = ib * 16 + i16, jB = jb * 16 + i16;
                     const T *fa = fbkSep + (itemA < nItems ? itemA : 0) * a.P;
                     const T *db = dctT + (jB < JW ? jB : 0) * a.dctPitch;
@@ -1154,6 +1156,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                         if (item < nItems && jB < JW) feat[item * a.D + jB] = acc[r] * a.mfnorm;
                     }
                 }
+            }
             team_sync<TEAM>();
         }
         STAMP(8);
