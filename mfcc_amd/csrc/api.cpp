@@ -444,7 +444,7 @@ static int choose_tile(MFCCPlan *p)
         // staging area: the tile's rows plus one 16-byte vector of slack for the alignment shift
         const size_t feat = (((size_t)ft * c->vSize + 3) & ~(size_t)3) + 4;
         fbkEl = c->cfg.fbankFlag ? 0 : (int)(((size_t)ft * V * P + 3) & ~(size_t)3);
-        teamEl = (int)((size_t)V * rowPitch + rawOrZ + feat + fbkEl + 8 + (teams > 1 ? 64 : 256)); // + prefetch sink
+        teamEl = (int)((size_t)V * rowPitch + rawOrZ + feat + fbkEl + 16 + (teams > 1 ? 64 : 256)); // + sum slots + prefetch sink
         const size_t elems = (tabLds ? tabElems : 0) + (size_t)teams * teamEl;
         return elems * el;
     };

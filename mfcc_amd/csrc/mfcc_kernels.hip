@@ -108,6 +108,35 @@ __device__ __forceinline__ V group_sum(V v, V *scratch, int tid)
     }
 }
 
+// Group sums without barriers of their own.  Up to 64 lanes: group_part already returns the full
+// sum.  Wider groups: it returns the wave's sum and parks it in slot[wave]; group_total adds the
+// group's waves and may be called once a barrier has passed (every caller has one on its way).
+template <typename V, int G>
+__device__ __forceinline__ V group_part(V v, V *slot, int tt)
+{
+    if constexpr (G <= 64) {
+        return group_sum<V, G>(v, slot, tt);
+    } else {
+        v = group_sum<V, 64>(v, slot, tt);
+        if ((tt & 63) == 0) slot[tt >> 6] = v;
+        return v;
+    }
+}
+template <typename V, int G>
+__device__ __forceinline__ V group_total(V part, const V *slot, int tt)
+{
+    if constexpr (G <= 64) {
+        return part;
+    } else {
+        constexpr int WPG = G / 64;
+        const int w0 = (tt / G) * WPG;
+        V sum = slot[w0];
+#pragma unroll
+        for (int w = 1; w < WPG; ++w) sum += slot[w0 + w];
+        return sum;
+    }
+}
+
 __device__ __forceinline__ int lds_sample(const unsigned *raw, int p, int bps)
 {
     const int w = p >> 2;
@@ -564,8 +593,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     T *zbuf = rows + F_V * a.rowPitch;              // GT work areas; raw PCM bytes alias it
     T *featBase = zbuf + a.rawOrZElems;             // framesPerTile x vSize static features (+ VEC)
     T *fbkSep = featBase + a.featElems;             // framesPerTile x V x P log-mel values (cepstral mode)
-    T *red = fbkSep + a.fbkElems;                   // 8 elements for cross-wave sums
-    unsigned *warm = reinterpret_cast<unsigned *>(red + 8) + (tid & (TEAM - 1) & ~63); // prefetch sink, 4 B per lane
+    T *red = fbkSep + a.fbkElems;                   // 16 elements: 4 slots of per-wave sums
+    unsigned *warm = reinterpret_cast<unsigned *>(red + 16) + (tid & (TEAM - 1) & ~63); // prefetch sink, 4 B per lane
     unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
 
     const int bpi = F_channels * F_bps;
@@ -860,7 +889,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 te = e2.x + e2.y;
             }
             STAMP(2);
-            if (a.energyFlag) te = group_sum<T, G>(te, red, tt);
+            if (a.energyFlag) te = group_part<T, G>(te, red, tt);
             if (F_zc) { // sign changes between neighbours of the un-windowed frame (main.c:227)
 #pragma unroll
                 for (int i = 0; i < PPL; ++i) {
@@ -871,7 +900,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     zc += (c01 && s0 + 1 < a.wlen) ? 1 : 0; // pairs inside the frame only
                     zc += (c12 && s0 + 2 < a.wlen) ? 1 : 0;
                 }
-                zc = group_sum<int, G>(zc, reinterpret_cast<int *>(red), tt);
+                zc = group_part<int, G>(zc, reinterpret_cast<int *>(red + 4), tt);
             }
 
             // ---- nc-point complex FFT of z[n] = x[2n] + i x[2n+1]   (Realft mfcc.c:262-270)
@@ -936,8 +965,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     regTotal += pa[q] + pb[q];
                     regNum += (T)(k + 1) * pa[q] + (T)(k2 + 1) * pb[q];
                 }
-                regTotal = group_sum<T, G>(regTotal, red, tt);
-                regNum = group_sum<T, G>(regNum, red, tt);
+                regTotal = group_part<T, G>(regTotal, red + 8, tt);
+                regNum = group_part<T, G>(regNum, red + 12, tt);
             }
             STAMP(4);
             group_sync<G>(); // every lane has read its Z points: the work area can be reused
@@ -1003,11 +1032,13 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 group_sync<G>();
             }
             if (F_S == 0 && F_bright && active && l == 0)
-                fo[a.M + a.c0Flag + a.energyFlag + F_zc] = regNum / regTotal / (T)NC;
+                fo[a.M + a.c0Flag + a.energyFlag + F_zc] =
+                    group_total<T, G>(regNum, red + 12, tt) / group_total<T, G>(regTotal, red + 8, tt) / (T)NC;
             if (active && l == 0) {
-                if (a.energyFlag) fo[a.M + a.c0Flag] = tlog<T>(te);                // main.c:243
-                if (F_zc)
-                    fo[a.M + a.c0Flag + a.energyFlag] = (T)zc / (T)(a.wlen - 1);   // main.c:244
+                if (a.energyFlag) fo[a.M + a.c0Flag] = tlog<T>(group_total<T, G>(te, red, tt)); // main.c:243
+                if (F_zc)                                                           // main.c:244
+                    fo[a.M + a.c0Flag + a.energyFlag] =
+                        (T)group_total<int, G>(zc, reinterpret_cast<const int *>(red + 4), tt) / (T)(a.wlen - 1);
             }
 
             if constexpr (MELM) {
