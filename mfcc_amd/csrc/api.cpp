@@ -229,9 +229,8 @@ static int choose_tile(MFCCPlan *p)
     const int groups = front_groups(log2nc, pplog) / teams; // frames in flight per team
     const int lanes = front_lanes(log2nc, pplog);
     // work area of one frame: nc complex points with one pad point per 16, or the nc (t1, ek-t1)
-    // pairs followed by the 2 (P+1) segment sums, whichever is larger
-    int zPitch = (std::max(std::max(2 * (nc + nc / 16), 2 * nc + 2 * (c->cfg.bankNum + 1)),
-                                 nc + 2 * c->cfg.subBandEFlag) + 3) & ~3; // or nc powers + 2 S band sums
+    // pairs, the 2 (P+1) segment sums and the 2 S sub-band sums behind them, whichever is larger
+    int zPitch = (std::max(2 * (nc + nc / 16), 2 * nc + std::max(2 * (c->cfg.bankNum + 1), 16) + 2 * c->cfg.subBandEFlag) + 3) & ~3;
     p->zPitch = zPitch;
     {
         // Per-stage twiddle blocks, laid out as the kernel's fft_stages reads them: for a stage

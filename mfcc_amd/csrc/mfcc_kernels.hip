@@ -992,7 +992,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     int lpb = 1;
                     while (lpb * 2 * nseg <= G && lpb < 64) lpb *= 2;
                     const int perPass = G / lpb;
-                    T *bandE = Zt + NC;
+                    T *bandE = Zt + 2 * NC + 2 * (a.P + 1); // behind the mel segment sums
                     for (int b0 = 0; b0 < nseg; b0 += perPass) {
                         const int b = b0 + l / lpb, sl = l & (lpb - 1);
                         T e = 0, ek = 0;
@@ -1028,8 +1028,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 if (active && F_fftLength > 0) {                                   // main.c:247
                     const int at = a.M + a.c0Flag + a.energyFlag + F_zc + F_bright + F_S;
                     for (int q = l; q < F_fftLength; q += G) fo[at + q] = tsqrt<T>(Pw[q]);
+                    group_sync<G>(); // the per-bin products below overwrite the power values
                 }
-                group_sync<G>();
             }
             if (F_S == 0 && F_bright && active && l == 0)
                 fo[a.M + a.c0Flag + a.energyFlag + F_zc] =
@@ -1150,9 +1150,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             group_sync<G>();
 
             }
-            STAMP(6);
-            // the next round overwrites the work area: every lane of the frame is done with it
-            group_sync<G>();
+            STAMP(6); // the barrier that closed the mel phase also frees the work area for the next round
             STAMP(7);
         }
         team_sync<TEAM>();
