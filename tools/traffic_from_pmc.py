@@ -9,12 +9,14 @@ requests of wide streaming reads at 64 bytes, so it is doubled; WRITE_SIZE is ta
 import csv
 import glob
 import json
+import os
 import sys
 
 
 def per_launch(dirname, counter):
     vals = []
-    for path in glob.glob(dirname + "/*/*_counter_collection.csv"):
+    paths = sorted(glob.glob(dirname + "/*/*_counter_collection.csv"), key=os.path.getmtime)
+    for path in paths[-1:]:  # the newest run only: merged result directories keep older files
         for r in csv.DictReader(open(path)):
             if "k_front" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
