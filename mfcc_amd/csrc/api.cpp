@@ -48,6 +48,7 @@ struct MFCCPlan {
     int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0, teamElems = 0, numRegBlocks = 0;
     int tabElems = 0, winPad = 0, featElems = 0, fbkElems = 0, rowTail = 0;
     int blocksPerCu = 1, numCus = 256, pplog = 4;
+    int activeTeams = 1;
     int deltaSubRows = 0, deltaRedOffset = 0; // fused delta kernel geometry (0: not used)
     size_t deltaLds = 0;
     double *dBlockPartial = nullptr;
@@ -433,7 +434,7 @@ static int choose_tile(MFCCPlan *p)
     p->winPad = (c->tab.fftN + 2 + 3) & ~3; // window values, then zeros up to fftN + 2
     const size_t tabElems = (((size_t)p->winPad + 2 * (size_t)nc + (size_t)std::max(nc, 2) + (size_t)nc +
                               4 * (size_t)lanes * p->maxSeg * 4 / el + (size_t)c->dctElems) + 3) & ~(size_t)3;
-    int teamEl = 0, fbkEl = 0;
+    int teamEl = 0, fbkEl = 0, useTeams = teams;
     auto geometry = [&](int ft, bool tabLds, int &rowPitch, int &rawOrZ) {
         const long ninst = (long)(ft - 1) * c->cfg.inc + c->cfg.wlen + 1;
         rowPitch = (int)((ninst + rowTail + 3) & ~3L);
@@ -444,7 +445,7 @@ static int choose_tile(MFCCPlan *p)
         const size_t feat = (((size_t)ft * c->vSize + 3) & ~(size_t)3) + 4;
         fbkEl = c->cfg.fbankFlag ? 0 : (int)(((size_t)ft * V * P + 3) & ~(size_t)3);
         teamEl = (int)((size_t)V * rowPitch + rawOrZ + feat + fbkEl + 16 + (teams > 1 ? 64 : 256)); // + sum slots + prefetch sink
-        const size_t elems = (tabLds ? tabElems : 0) + (size_t)teams * teamEl;
+        const size_t elems = (tabLds ? tabElems : 0) + (size_t)useTeams * teamEl;
         return elems * el;
     };
     // Prefer the occupancy the registers allow, then LDS tables, then longer tiles.
@@ -463,13 +464,18 @@ static int choose_tile(MFCCPlan *p)
                     bestBlocks = blocks;
                 }
             }
-    for (int ft = base; ft >= 1 && !bestFt; --ft) {
-        int rp, rz;
-        if (geometry(ft, false, rp, rz) <= kLds) {
-            bestFt = ft;
-            bestBlocks = 1;
+    // Last resort: one workgroup per CU, shorter tiles, then fewer of the workgroup's teams at work.
+    for (int at = teams; at >= 1 && !bestFt; at /= 2) {
+        useTeams = at;
+        for (int ft = base; ft >= 1 && !bestFt; --ft) {
+            int rp, rz;
+            if (geometry(ft, false, rp, rz) <= kLds) {
+                bestFt = ft;
+                bestBlocks = 1;
+            }
         }
     }
+    if (!bestFt) useTeams = teams;
     if (const char *e = getenv("MFCC_TILE")) { // tuning aid: "<framesPerTile>,<tablesInLds>,<workgroupsPerCu>"
         int ft = 0, tab = 0, blocks = 0;
         if (sscanf(e, "%d,%d,%d", &ft, &tab, &blocks) == 3 && ft > 0 && blocks > 0) {
@@ -487,6 +493,7 @@ static int choose_tile(MFCCPlan *p)
     p->blocksPerCu = bestBlocks;
     p->ldsBytes = geometry(bestFt, bestTab, p->rowPitch, p->rawOrZElems);
     p->teamElems = teamEl;
+    p->activeTeams = useTeams;
     p->fbkElems = fbkEl;
     p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
     // Lean instantiation: mono 16-bit input, one row, even frame shift, none of the per-frame extras.
@@ -594,9 +601,9 @@ static int finish_plan(MFCCPlan *p)
     // Fused delta (+ statistics) pass: orders 2 and 3, rows of at most one workgroup of columns,
     // two LDS tiles of (subRows + 2 halo) rows within 64 KiB.
     p->deltaSubRows = 0;
-    if ((c->cfg.regreOrder == 2 || c->cfg.regreOrder == 3) && c->vSize <= kBlock && !getenv("MFCC_NO_FUSED_DELTA")) {
+    if (c->cfg.regreOrder >= 2 && c->vSize <= kBlock && !getenv("MFCC_NO_FUSED_DELTA")) {
         const size_t elb = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
-        const int halo = (c->cfg.regreOrder - 1) * c->cfg.delwin;
+        const int halo = (std::min(c->cfg.regreOrder, 3) - 1) * c->cfg.delwin;
         for (int sr = 256; sr >= 8 && !p->deltaSubRows; sr /= 2) {
             const size_t tiles = (2 * (size_t)(sr + 2 * halo) * c->vSize * elb + 15) & ~(size_t)15;
             if (tiles + 2 * kBlock * sizeof(double) <= 64 * 1024 && sr >= c->cfg.delwin) {
@@ -606,7 +613,7 @@ static int finish_plan(MFCCPlan *p)
             }
         }
     }
-    if (p->deltaSubRows && c->cfg.znormFlag && !p->shard)
+    if (p->deltaSubRows && c->cfg.znormFlag && !p->shard && c->cfg.regreOrder <= 3) // sums of every column
         HIP_TRY(hipMalloc((void **)&p->dBlockPartial, std::max<size_t>(regUtt.size(), 1) * 2 * c->step * sizeof(double)));
     const bool needStats = c->cfg.znormFlag != 0;
     if (needStats) {
@@ -848,6 +855,7 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.rowTail = p->rowTail;
     a.rawOrZElems = p->rawOrZElems;
     a.teamElems = p->teamElems;
+    a.activeTeams = p->activeTeams;
     a.tabElems = p->tabElems;
     a.winPad = p->winPad;
     a.featElems = p->featElems;
@@ -876,7 +884,7 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     }
 #endif
     // persistent workgroups: as many as stay resident, each walks tiles with a grid stride
-    const int teams = front_teams(c->tab.log2nc, p->pplog);
+    const int teams = p->activeTeams;
     const int blocks = (int)std::min<int64_t>((p->numTiles + teams - 1) / teams, (int64_t)p->numCus * p->blocksPerCu);
     const int rc = launch_front(c->cfg.precision, c->tab.log2nc, p->pplog, &a, blocks, p->ldsBytes, stream);
     if (rc) return set_error("static-feature kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
@@ -889,7 +897,7 @@ static int run_regress(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
     double sigmaT2 = 0.0;
     for (int t = 1; t <= c->cfg.delwin; ++t) sigmaT2 += (double)t * t;
     sigmaT2 *= 2.0;
-    for (int order = 2; order <= c->cfg.regreOrder; ++order) { /* main.c:259-260 */
+    for (int order = 2; order <= std::min(c->cfg.regreOrder, 3); ++order) { /* main.c:259-260: two calls at most */
         RegressArgs<T> a;
         memset(&a, 0, sizeof a);
         a.data = static_cast<T *>(outDev);
@@ -928,7 +936,7 @@ static int run_delta(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
     a.redOffset = p->deltaRedOffset;
     a.sigmaT2 = 2.0 * sigmaT2;
     a.partial = p->dBlockPartial;
-    const int rc = launch_delta(c->cfg.precision, &a, c->cfg.regreOrder, p->deltaLds, stream);
+    const int rc = launch_delta(c->cfg.precision, &a, std::min(c->cfg.regreOrder, 3), p->deltaLds, stream);
     if (rc) return set_error("delta kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;
 }
@@ -997,6 +1005,10 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
         if (rc) return set_error("row-mean kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     }
     const bool f64 = c->cfg.precision == MFCC_PREC_F64;
+    // The reference fills the delta and delta-delta slots only (main.c:259-260); slots of higher
+    // orders keep their initial value, taken as zero here.
+    if (c->cfg.regreOrder > 3)
+        HIP_TRY(hipMemsetAsync(outDev, 0, (size_t)p->totalRows * c->step * (f64 ? 8 : 4), st));
     if (p->timing) HIP_TRY(hipEventRecord(p->evStart, st));
     rc = f64 ? run_front<double>(c, p, pcmDev, outDev, stream) : run_front<float>(c, p, pcmDev, outDev, stream);
     if (rc) return rc;

@@ -75,6 +75,7 @@ struct FrontArgs {
     int rowTail;           // elements zero-filled behind the last sample of a tile (>= fftN - wlen + 1)
     int rawOrZElems;       // elements reserved for max(raw PCM bytes, a team's work areas)
     int teamElems;         // elements of one team's LDS region (rows, work areas, staging, sums)
+    int activeTeams;       // teams of a workgroup that take tiles (1 .. teams per workgroup)
     int tabElems;          // elements of the LDS copy of the tables (0: tables are read through L1/L2)
     int winPad;            // elements reserved for the window inside that copy
     int featElems;         // elements of the static-feature staging area (framesPerTile x vSize, padded)

@@ -683,8 +683,10 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 #pragma unroll
     for (int j = 0; j < PFN; ++j) pf[j] = u4u{0u, 0u, 0u, 0u};
 
-    const int tstride = gridDim.x * NTEAMS;
-    int tile = blockIdx.x * NTEAMS + team;
+    // Only the first activeTeams teams of a workgroup take tiles (fewer than NTEAMS when the
+    // team regions of all of them would not fit the LDS); the others leave here.
+    const int tstride = gridDim.x * a.activeTeams;
+    int tile = team < a.activeTeams ? blockIdx.x * a.activeTeams + team : a.numTiles;
     TileDesc td = {0, 0};
     if (tile < a.numTiles) td = a.tiles[tile];
     for (; tile < a.numTiles; tile += tstride) {

@@ -24,6 +24,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _pcm(n, ch, bps, seed, sr, tone=440):
+    if bps == 4:  # the generator makes 16- and 24-bit samples: widen 24-bit ones, low byte varied
+        p24 = ma.synth_pcm(n, ch, 3, seed=0x5EED0000 + seed, sample_rate=sr, tone_hz=tone).reshape(-1, 3)
+        out = np.empty((p24.shape[0], 4), dtype=np.uint8)
+        out[:, 1:] = p24
+        out[:, 0] = p24[:, 0] ^ 0x5A
+        return out.reshape(-1)
     return ma.synth_pcm(n, ch, bps, seed=0x5EED0000 + seed, sample_rate=sr, tone_hz=tone)
 
 
@@ -112,6 +118,48 @@ def test_lean_kernel_modes(oracle, wlen, bank, cepstral):
     assert ref.shape[0] == 37
     got = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], 1, 2)[0]
     _compare(got, ref, kw, False)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configurations(oracle, seed):
+    """Seeded random walk over the option space (frame geometry, channel layouts, feature flags,
+    delta orders and windows, z-norm, batches of ragged utterances at odd byte offsets): whichever
+    kernel mode, tile geometry and delta path the plan picks must agree with the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    sr = int(rng.choice([8000, 16000, 44100]))
+    wlen = int(rng.choice([64, 200, 256, 400, 441, 512, 800, 1024, 1764, 2048]))
+    inc = int(max(1, wlen // int(rng.choice([2, 3, 4])) + int(rng.integers(-1, 2))))
+    ch = int(rng.choice([1, 2]))
+    bps = int(rng.choice([2, 2, 3, 4]))
+    vec = int(rng.integers(1, 5)) if ch == 2 else 1
+    bank = int(rng.integers(3, 50))
+    fbank = int(rng.integers(0, 2))
+    order = int(rng.choice([1, 1, 2, 3, 4]))
+    plain = bool(rng.integers(0, 2))  # half of the draws stay inside the lean kernel's option set
+    kw = dict(sampleRate=sr, lowpassfre=-1, hipassfre=-1, preemphasise=float(rng.choice([0.0, 0.95, 0.97])),
+              wlen=wlen, inc=inc, vecNum=vec, fbankFlag=fbank, bankNum=bank, MFCCNum=int(rng.integers(1, bank + 1)),
+              MFCC0thFlag=int(rng.integers(0, 2)), energyFlag=int(rng.integers(0, 2)),
+              zeroCrossingFlag=0 if plain else int(rng.integers(0, 2)),
+              brightFlag=0 if plain else int(rng.integers(0, 2)),
+              subBandEFlag=0 if plain else int(rng.choice([0, 0, 3, 8])),
+              fftLength=0 if plain else int(rng.choice([0, 0, 5])),
+              regreOrder=order, delwin=int(rng.integers(1, 6)) if order > 1 else 0,
+              zeroMeanSigFlag=0 if plain else int(rng.integers(0, 2)), znormFlag=int(rng.integers(0, 2)))
+    if plain:
+        ch, bps, kw["vecNum"] = 1, 2, 1
+        if kw["inc"] % 2:
+            kw["inc"] += 1
+    lengths = [int(wlen + kw["inc"] * rng.integers(0, 60) + rng.integers(0, kw["inc"])) for _ in range(3)] + [wlen - 1]
+    pcms = [_pcm(n, ch, bps, seed * 10 + i, sr, tone=0).tobytes() for i, n in enumerate(lengths)]
+    ocfg = oracle.make_config(**kw)
+    refs = [oracle.extract_pcm_bytes(ocfg, np.frombuffer(p, dtype=np.uint8), ch, bps) for p in pcms]
+    for f64 in (False, True):
+        cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+        gots = run_product_batch(ma, cfg, pcms, ch, bps, pad=int(rng.integers(0, 7)))
+        for got, ref in zip(gots, refs):
+            assert got.shape == ref.shape
+            if ref.shape[0] >= 5 or not kw["znormFlag"]:  # z-norm over a few rows magnifies last-bit differences (0/0 vs +-1)
+                _compare(got, ref, kw, f64)
 
 
 def test_ragged_batch_and_edge_lengths(oracle):
