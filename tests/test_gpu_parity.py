@@ -120,7 +120,7 @@ def test_lean_kernel_modes(oracle, wlen, bank, cepstral):
     _compare(got, ref, kw, False)
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MFCC_FUZZ_SEEDS", "48"))))
 def test_random_configurations(oracle, seed):
     """Seeded random walk over the option space (frame geometry, channel layouts, feature flags,
     delta orders and windows, z-norm, batches of ragged utterances at odd byte offsets): whichever
