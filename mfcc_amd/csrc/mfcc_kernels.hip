@@ -606,18 +606,25 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     if constexpr (TLDS) {
         T *w = ldsTab, *t = w + a.winPad, *sp = t + 2 * NC, *lo = sp + (NC > 1 ? NC : 2);
         int *c = reinterpret_cast<int *>(lo + NC);
-        for (int i = tid; i < a.winPad; i += kBlock) w[i] = a.window[i];
+        // (the lean modes read window, split factors and mel weights once from global memory into
+        // registers, and the matrix-core mel needs no segment map: those copies are skipped)
+        if constexpr (!LEAN) {
+            for (int i = tid; i < a.winPad; i += kBlock) w[i] = a.window[i];
+            for (int i = tid; i < (NC > 1 ? NC : 2); i += kBlock) sp[i] = a.splitTw[i];
+            for (int i = tid; i < NC; i += kBlock) lo[i] = a.loWt[i];
+        }
         for (int i = tid; i < 2 * NC; i += kBlock) t[i] = a.tw[i];
-        for (int i = tid; i < (NC > 1 ? NC : 2); i += kBlock) sp[i] = a.splitTw[i];
-        for (int i = tid; i < NC; i += kBlock) lo[i] = a.loWt[i];
-        for (int i = tid; i < 4 * G * a.maxSeg; i += kBlock) c[i] = a.laneSeg[i];
+        if constexpr (!MELM)
+            for (int i = tid; i < 4 * G * a.maxSeg; i += kBlock) c[i] = a.laneSeg[i];
         T *dl = reinterpret_cast<T *>(c + 4 * G * a.maxSeg);
         for (int i = tid; i < a.dctElems; i += kBlock) dl[i] = a.dctT[i];
         dctT = dl;
-        win = w;
         tw = t;
-        split = sp;
-        lw = lo;
+        if constexpr (!LEAN) {
+            win = w;
+            split = sp;
+            lw = lo;
+        }
         lseg = reinterpret_cast<const int4 *>(c);
         __syncthreads();
     }
