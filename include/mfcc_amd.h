@@ -219,6 +219,29 @@ int MFCCShardNormalize(MFCCContext *ctx, MFCCPlan *plan, void *outDev, const dou
 int MFCCChannelSums(MFCCContext *ctx, const void *pcmDev, int channels, int bytesPerSample,
                     int64_t sampleBegin, int64_t count, int64_t *sums2Dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The reference's lower-level API (mfcc.h:29-74), batched on the device: numFrames vectors back
+ * to back in device memory, 0-based (the reference's 1-based Vector element [i] is element
+ * [i-1] here), float or double as `precision` / the context says; asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------ */
+
+/* FFT (mfcc.c:211-259) in place on numFrames vectors of n reals = n/2 complex points
+ * (re, im interleaved); forward sign e^{+i theta}; invert != 0 divides by n/2. */
+int MFCCFFTDevice(int precision, void *dataDev, int numFrames, int n, int invert, void *stream);
+/* Realft (mfcc.c:262-291) in place on numFrames vectors of n reals: packed spectrum, element 0 =
+ * Re X0 + Im X0 as the reference leaves it, element 1 = 0. */
+int MFCCRealftDevice(int precision, void *dataDev, int numFrames, int n, void *stream);
+/* Wave2FBank (mfcc.c:125-177): numFrames windowed frames of cfg.wlen samples -> numFrames x bankNum
+ * log filterbank values (usePower = 1, floor 1.0) and, if teDev != NULL, the frame energies. */
+int MFCCWave2FBankDevice(MFCCContext *ctx, const void *framesDev, int numFrames, void *fbankDev,
+                         void *teDev, void *stream);
+/* FBank2MFCC (mfcc.c:180-195) and, if c0Dev != NULL, FBank2C0 (mfcc.c:197-208): numFrames x bankNum
+ * -> numFrames x MFCCNum values (C0: numFrames values).  The context must not be in filterbank mode. */
+int MFCCFBank2MFCCDevice(MFCCContext *ctx, const void *fbankDev, int numFrames, void *mfccDev,
+                         void *c0Dev, void *stream);
+/* Mel (mfcc.c:11-15): mel value of the 1-based FFT bin k. */
+double MFCCMel(int k, double fres);
+
 /* Elapsed milliseconds the dominant (static feature) kernel took in the most recent
  * MFCCExtractDevice on this plan, measured with HIP events on the launch stream; synchronises
  * on the stop event.  Negative when timing was not enabled with MFCCPlanEnableTiming. */

@@ -70,6 +70,7 @@ EXPORTS = [
     "MFCCPlanSampleBegin", "MFCCPlanSampleCount", "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows",
     "MFCCExtractDevice", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
     "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm", "MFCCFormatValue",
+    "MFCCFFTDevice", "MFCCRealftDevice", "MFCCWave2FBankDevice", "MFCCFBank2MFCCDevice", "MFCCMel",
 ]
 
 
@@ -136,6 +137,12 @@ def lib():
     L.MFCCSynthPcm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_int,
                                C.c_int]
     L.MFCCFormatValue.argtypes = [C.c_double, C.c_int, C.c_char_p, C.c_size_t]
+    L.MFCCFFTDevice.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.MFCCRealftDevice.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp]
+    L.MFCCWave2FBankDevice.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.MFCCFBank2MFCCDevice.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.MFCCMel.argtypes = [C.c_int, C.c_double]
+    L.MFCCMel.restype = C.c_double
     _lib = L
     return L
 
@@ -206,6 +213,38 @@ def format_value(x, save_type):
     if n < 0:
         _check(n)
     return buf.raw[:n].decode()
+
+
+def _prec_of(t):
+    import torch
+    if t.dtype == torch.float64:
+        return PREC_F64
+    if t.dtype == torch.float32:
+        return PREC_F32
+    raise TypeError("float32 or float64 tensor expected")
+
+
+def fft_device(data, invert=False):
+    """In-place batched FFT (mfcc.c:211-259) of a [n, 2*nc] device tensor of interleaved (re, im)."""
+    import torch
+    assert data.is_contiguous() and data.dim() == 2
+    st = torch.cuda.current_stream(data.device).cuda_stream
+    _check(lib().MFCCFFTDevice(_prec_of(data), data.data_ptr(), data.shape[0], data.shape[1], int(invert),
+                               C.c_void_p(st)))
+    return data
+
+
+def realft_device(data):
+    """In-place batched Realft (mfcc.c:262-291) of a [n, fftN] device tensor."""
+    import torch
+    assert data.is_contiguous() and data.dim() == 2
+    st = torch.cuda.current_stream(data.device).cuda_stream
+    _check(lib().MFCCRealftDevice(_prec_of(data), data.data_ptr(), data.shape[0], data.shape[1], C.c_void_p(st)))
+    return data
+
+
+def mel(k, fres):
+    return float(lib().MFCCMel(int(k), float(fres)))
 
 
 def synth_pcm(num_samples, channels=1, bytes_per_sample=2, seed=0x5EED0000, sample_rate=16000,
@@ -330,6 +369,38 @@ class Context:
                                        lo_chan.ctypes.data_as(C.POINTER(C.c_int)),
                                        lo_wt.ctypes.data_as(C.POINTER(C.c_double))))
         return dict(fftN=fft_n.value, klo=klo.value, khi=khi.value, cf=cf, loChan=lo_chan, loWt=lo_wt)
+
+    # -- the reference's lower-level API, batched: torch tensors on the context's device ----------
+
+    def _dtype(self):
+        import torch
+        return torch.float64 if self.precision == PREC_F64 else torch.float32
+
+    def wave2fbank(self, frames):
+        """frames: [n, wlen] windowed frames -> ([n, bankNum] log filterbank values, [n] energies)."""
+        import torch
+        frames = frames.contiguous()
+        assert frames.dtype == self._dtype() and frames.shape[1] == self.cfg.wlen
+        n = frames.shape[0]
+        fb = torch.empty((n, self.cfg.bankNum), dtype=frames.dtype, device=frames.device)
+        te = torch.empty((n,), dtype=frames.dtype, device=frames.device)
+        st = torch.cuda.current_stream(frames.device).cuda_stream
+        _check(lib().MFCCWave2FBankDevice(self.handle, frames.data_ptr(), n, fb.data_ptr(), te.data_ptr(),
+                                          C.c_void_p(st)))
+        return fb, te
+
+    def fbank2mfcc(self, fbank):
+        """fbank: [n, bankNum] -> ([n, MFCCNum] cepstra, [n] C0)."""
+        import torch
+        fbank = fbank.contiguous()
+        assert fbank.dtype == self._dtype() and fbank.shape[1] == self.cfg.bankNum
+        n = fbank.shape[0]
+        m = torch.empty((n, self.cfg.MFCCNum), dtype=fbank.dtype, device=fbank.device)
+        c0 = torch.empty((n,), dtype=fbank.dtype, device=fbank.device)
+        st = torch.cuda.current_stream(fbank.device).cuda_stream
+        _check(lib().MFCCFBank2MFCCDevice(self.handle, fbank.data_ptr(), n, m.data_ptr(), c0.data_ptr(),
+                                          C.c_void_p(st)))
+        return m, c0
 
     def close(self):
         if self.handle:

@@ -36,6 +36,7 @@ struct MFCCContext {
     int M = 0, c0 = 0, D = 0, vSize = 0, step = 0;
     void *dWindow = nullptr, *dTw = nullptr, *dSplitTw = nullptr, *dLoWt = nullptr, *dDct = nullptr;
     int dctPitch = 0, dctElems = 0;
+    int32_t *dLoChan = nullptr; // bin -> lower channel, for the batched Wave2FBank entry point
 };
 
 struct MFCCPlan {
@@ -140,6 +141,8 @@ extern "C" int MFCCContextCreate(const MFCCConfig *cfgIn, int device, MFCCContex
                     tr[(size_t)j * c->dctPitch + k] = j < M ? c->tab.dct[(size_t)k * M + j] : 1.0;
         if ((rc = upload_tab(p, tr, &c->dDct))) return rc;
     }
+    HIP_TRY(hipMalloc((void **)&c->dLoChan, std::max<size_t>(c->tab.loChan.size(), 1) * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(c->dLoChan, c->tab.loChan.data(), c->tab.loChan.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     *out = c.release();
     return MFCC_OK;
 }
@@ -153,6 +156,7 @@ extern "C" void MFCCContextDestroy(MFCCContext *c)
     (void)hipFree(c->dSplitTw);
     (void)hipFree(c->dLoWt);
     (void)hipFree(c->dDct);
+    (void)hipFree(c->dLoChan);
     delete c;
 }
 
@@ -1077,6 +1081,58 @@ extern "C" int MFCCChannelSums(MFCCContext *c, const void *pcmDev, int channels,
     if (rc) return set_error("channel-sum kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// the reference's lower-level API, batched on the device
+// ------------------------------------------------------------------------------------------
+
+static bool pow2_between(int n, int lo, int hi) { return n >= lo && n <= hi && (n & (n - 1)) == 0; }
+
+extern "C" int MFCCFFTDevice(int precision, void *dataDev, int numFrames, int n, int invert, void *stream)
+{
+    if (numFrames < 0 || (numFrames > 0 && !dataDev) || !pow2_between(n, 2, 2 << kMaxLog2Nc))
+        return set_error("bad argument to MFCCFFTDevice (n must be a power of two, 2..%d)", 2 << kMaxLog2Nc), MFCC_E_ARG;
+    const int rc = launch_fft_batch(precision == MFCC_PREC_F64, dataDev, numFrames, n, invert ? 1 : 0, 0, stream);
+    if (rc) return set_error("FFT kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+extern "C" int MFCCRealftDevice(int precision, void *dataDev, int numFrames, int n, void *stream)
+{
+    if (numFrames < 0 || (numFrames > 0 && !dataDev) || !pow2_between(n, 4, 2 << kMaxLog2Nc))
+        return set_error("bad argument to MFCCRealftDevice (n must be a power of two, 4..%d)", 2 << kMaxLog2Nc), MFCC_E_ARG;
+    const int rc = launch_fft_batch(precision == MFCC_PREC_F64, dataDev, numFrames, n, 0, 1, stream);
+    if (rc) return set_error("Realft kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+extern "C" int MFCCWave2FBankDevice(MFCCContext *c, const void *framesDev, int numFrames, void *fbankDev,
+                                    void *teDev, void *stream)
+{
+    if (!c || numFrames < 0 || (numFrames > 0 && (!framesDev || !fbankDev)))
+        return set_error("bad argument to MFCCWave2FBankDevice"), MFCC_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const int rc = launch_wave2fbank_batch(c->cfg.precision == MFCC_PREC_F64, framesDev, fbankDev, teDev, numFrames,
+                                           c->cfg.wlen, c->tab.fftN, c->tab.klo, c->tab.khi, c->cfg.bankNum,
+                                           c->dLoChan, c->dLoWt, stream);
+    if (rc) return set_error("Wave2FBank kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+extern "C" int MFCCFBank2MFCCDevice(MFCCContext *c, const void *fbankDev, int numFrames, void *mfccDev,
+                                    void *c0Dev, void *stream)
+{
+    if (!c || numFrames < 0 || (numFrames > 0 && (!fbankDev || !mfccDev)))
+        return set_error("bad argument to MFCCFBank2MFCCDevice"), MFCC_E_ARG;
+    if (c->cfg.fbankFlag) return set_error("the context is in filterbank mode (fbankFlag): it has no cepstral table"), MFCC_E_CONFIG;
+    HIP_TRY(hipSetDevice(c->device));
+    const int rc = launch_fbank2mfcc_batch(c->cfg.precision == MFCC_PREC_F64, fbankDev, mfccDev, c0Dev, numFrames,
+                                           c->cfg.bankNum, c->M, c->dDct, c->dctPitch, c->tab.mfnorm, stream);
+    if (rc) return set_error("FBank2MFCC kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+extern "C" double MFCCMel(int k, double fres) { return 1127 * log(1 + (k - 1) * fres); } /* mfcc.c:11-15 */
 
 // ------------------------------------------------------------------------------------------
 // file-level entry points

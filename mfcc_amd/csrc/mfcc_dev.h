@@ -135,6 +135,13 @@ int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, dou
 int launch_delta(int precision, const void *args, int orders, size_t ldsBytes, void *stream); // -2: no such variant
 int launch_normalize(int precision, const void *args, int numChunks, bool shardSums,
                      const double *sums, void *stream);
+// batched pieces of the reference's lower-level API (pieces.hip)
+int launch_fft_batch(int precision, void *data, int numFrames, int n, int invert, int realft, void *stream);
+int launch_wave2fbank_batch(int precision, const void *frames, void *fbank, void *te, int numFrames,
+                            int frameSize, int fftN, int klo, int khi, int P, const int *loChan,
+                            const void *loWt, void *stream);
+int launch_fbank2mfcc_batch(int precision, const void *fbank, void *mfcc, void *c0, int numFrames, int P,
+                            int M, const void *dctT, int dctPitch, double mfnorm, void *stream);
 int launch_chansums(const unsigned char *pcm, int channels, int bps, int64_t firstByte,
                     int64_t count, unsigned long long *sums2 /*4, pre-zeroed*/, void *stream);
 int launch_uttmeans(const unsigned char *pcm, UttDesc *utts, int numUtts, int channels, int bps,

@@ -381,3 +381,49 @@ def test_kernel_timing_api():
     plan.extract(torch.from_numpy(pcm).cuda())
     ms = plan.last_kernel_ms()
     assert 0 < ms < 1000
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_lower_level_api_pieces(oracle, precision):
+    """FFT, Realft, Wave2FBank, FBank2MFCC / FBank2C0 (mfcc.h:29-74) as batched device calls against
+    the oracle's restatements of the same functions."""
+    import torch
+    f64 = precision == "f64"
+    dt = torch.float64 if f64 else torch.float32
+    rng = np.random.default_rng(77)
+    for n in (2, 4, 16, 512, 2048, 16384):
+        x = rng.standard_normal((5, n))
+        tol = (1e-11 if f64 else 2e-5) * np.sqrt(n) * 4
+        for inv in (0, 1):
+            want = np.stack([oracle.fft(r, inv) for r in x])
+            got = ma.fft_device(torch.tensor(x, dtype=dt, device="cuda"), bool(inv)).double().cpu().numpy()
+            assert np.max(np.abs(got - want)) < tol * (1 if not inv else 2.0 / n + 1e-3), (n, inv)
+        if n >= 4:
+            want = np.stack([oracle.realft(r) for r in x])
+            got = ma.realft_device(torch.tensor(x, dtype=dt, device="cuda")).double().cpu().numpy()
+            assert np.max(np.abs(got - want)) < tol, n
+            assert np.all(got[:, 1] == 0.0)
+    kw = dict(CONFIGS["c3"])
+    cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+    ctx = ma.Context(cfg, 0)
+    frames = rng.standard_normal((33, kw["wlen"])) * 3000.0
+    frames[0] = 0.0                         # silence: every channel at the floor
+    frames[1] = 0.0
+    frames[1, 7] = 12345.0                  # single impulse
+    fb, te = ctx.wave2fbank(torch.tensor(frames, dtype=dt, device="cuda"))
+    fb, te = fb.double().cpu().numpy(), te.double().cpu().numpy()
+    for i, fr in enumerate(frames):
+        wf, wte, _, _ = oracle.wave2fbank(fr, kw["sampleRate"], kw["bankNum"], kw["lowpassfre"], kw["hipassfre"])
+        assert np.max(np.abs(fb[i] - wf)) < (1e-10 if f64 else 1e-4), i
+        assert abs(te[i] - wte) <= (1e-12 if f64 else 1e-5) * max(wte, 1.0), i
+    fbank = rng.standard_normal((40, kw["bankNum"])) * 5 + 10
+    m, c0 = ctx.fbank2mfcc(torch.tensor(fbank, dtype=dt, device="cuda"))
+    m, c0 = m.double().cpu().numpy(), c0.double().cpu().numpy()
+    for i, f in enumerate(fbank):
+        wm, wc0 = oracle.fbank2mfcc(f, kw["MFCCNum"])
+        scale = max(1.0, float(np.max(np.abs(wm))))
+        assert np.max(np.abs(m[i] - wm)) < (1e-11 if f64 else 1e-5) * scale
+        assert abs(c0[i] - wc0) < (1e-11 if f64 else 1e-5) * max(1.0, abs(wc0))
+    ctx.close()
+    fres = 1.0e7 / (1e7 / 16000 * 512 * 700.0)
+    assert abs(ma.mel(17, fres) - 1127 * np.log(1 + 16 * fres)) < 1e-12

@@ -48,7 +48,7 @@ delwin = 9 ;
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "mfcc_amd.h")).read()
-    declared = set(re.findall(r"\b(MFCC[A-Za-z]+)\s*\(", header))
+    declared = set(re.findall(r"\b(MFCC[A-Za-z0-9]+)\s*\(", header))
     declared -= {"MFCCConfig"}
     L = ma.lib()
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
