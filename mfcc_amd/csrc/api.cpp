@@ -7,6 +7,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -1293,53 +1297,142 @@ struct ListItem {
     std::vector<unsigned char> file;
     WavInfo w;
     int status = MFCC_OK;
+    bool announced = false;
     std::string message;
 };
 
-// Extracts and writes items [b, e), all of one PCM layout.
-void run_group(MFCCContext *c, const MFCCConfig &cfg, std::vector<ListItem> &items, size_t b, size_t e)
+// Runs fn(i) for i in [0, n) on up to nth threads (the calling thread is one of them).
+template <typename F>
+void parallel_for(size_t n, int nth, F fn)
 {
-    const int channels = items[b].w.channels, bps = items[b].w.bytesPerSample;
-    std::vector<int64_t> off, ns, rowOff, frames;
-    size_t total = 0;
-    for (size_t i = b; i < e; ++i) {
-        off.push_back((int64_t)total);
-        ns.push_back(items[i].w.numSamples);
-        total += ((size_t)items[i].w.numSamples * channels * bps + 15) & ~(size_t)15;
-    }
-    std::vector<unsigned char> packed(std::max<size_t>(total, 16));
-    for (size_t i = b; i < e; ++i)
-        memcpy(packed.data() + off[i - b], items[i].file.data() + items[i].w.dataOffset,
-               (size_t)items[i].w.numSamples * channels * bps);
-    std::vector<double> rows;
-    const int rc = extract_packed(c, packed.data(), total, channels, bps, off, ns, rows, rowOff, frames);
-    if (rc) {
-        for (size_t i = b; i < e; ++i) {
-            items[i].status = rc;
-            items[i].message = MFCCLastError();
-        }
-        return;
-    }
-    // writers: text formatting dominates, so spread the files over numThreads host threads
-    const int nth = std::max(1, std::min<int>(cfg.numThreads, (int)(e - b)));
+    nth = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(nth, 1), n));
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+    };
     std::vector<std::thread> pool;
-    for (int t = 0; t < nth; ++t)
-        pool.emplace_back([&, t]() {
-            for (size_t i = b + t; i < e; i += nth) {
-                const size_t u = i - b;
-                const int wrc = MFCCWriteFeatures(items[i].dst.c_str(), rows.data() + (size_t)rowOff[u] * c->step,
-                                                  (long)frames[u], c->step, cfg.saveType);
-                if (wrc) {
-                    items[i].status = wrc;
-                    items[i].message = MFCCLastError();
-                }
-            }
-        });
+    for (int t = 1; t < nth; ++t) pool.emplace_back(work);
+    work();
     for (auto &th : pool) th.join();
+}
+
+// Grow-only page-locked host buffer / device buffer
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return MFCC_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr, cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return MFCC_OK;
+    }
+    ~PinnedBuf()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+};
+struct GrowDevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return MFCC_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr, cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return MFCC_OK;
+    }
+    ~GrowDevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+};
+
+// One batch of list items of a single PCM layout on its way through the stages
+// read+pack -> device -> write.
+struct ListBatch {
+    std::vector<size_t> idx; // positions in the item list
+    int channels = 0, bps = 0;
+    std::vector<int64_t> off, ns, rowOff, frames;
+    size_t pcmBytes = 0;
+    PinnedBuf hPcm, hOut;
+    int rc = MFCC_OK;
+    std::string message;
+};
+
+template <typename T>
+class BlockingQueue {
+public:
+    void push(T v)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            q_.push_back(v);
+        }
+        cv_.notify_one();
+    }
+    T pop()
+    {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [&] { return !q_.empty(); });
+        T v = q_.front();
+        q_.pop_front();
+        return v;
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+};
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Device stage of one batch: upload, extract, download (asynchronous copies from and to
+// page-locked memory on the stage's own stream).
+int list_device_stage(MFCCContext *c, ListBatch &b, GrowDevBuf &dPcm, GrowDevBuf &dOut, hipStream_t st)
+{
+    MFCCPlan *plan = nullptr;
+    int rc = MFCCPlanCreate(c, b.channels, b.bps, (int)b.off.size(), b.off.data(), b.ns.data(), &plan);
+    if (rc) return rc;
+    std::unique_ptr<MFCCPlan, void (*)(MFCCPlan *)> guard(plan, MFCCPlanDestroy);
+    const size_t n = b.off.size();
+    b.rowOff.resize(n);
+    b.frames.resize(n);
+    for (size_t u = 0; u < n; ++u) {
+        b.rowOff[u] = MFCCPlanRowOffset(plan, (int)u);
+        b.frames[u] = MFCCPlanNumFrames(plan, (int)u);
+    }
+    const int64_t rows = MFCCPlanTotalRows(plan);
+    if (rows == 0) return MFCC_OK;
+    const size_t el = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
+    const size_t outBytes = (size_t)rows * c->step * el;
+    if ((rc = b.hOut.ensure(outBytes))) return rc;
+    if ((rc = dPcm.ensure(b.pcmBytes + 16))) return rc;
+    if ((rc = dOut.ensure(outBytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(dPcm.p, b.hPcm.p, b.pcmBytes, hipMemcpyHostToDevice, st));
+    if ((rc = MFCCExtractDevice(c, plan, dPcm.p, b.pcmBytes, dOut.p, st))) return rc;
+    HIP_TRY(hipMemcpyAsync(b.hOut.p, dOut.p, outBytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MFCC_OK;
 }
 
 } // namespace
 
+// The reference's whole run (main.c:98-300) as a three-stage pipeline over batches of files:
+// the calling thread reads and parses files (numThreads readers) and packs their PCM payloads
+// into page-locked memory; a device thread uploads, extracts and downloads; a writer thread
+// formats and writes the feature files (numThreads writers).  Three batches are in flight, so
+// file reads, PCIe copies, kernels and writers of neighbouring batches overlap.
 extern "C" int MFCCWapperList(const char *iniPath)
 {
     MFCCConfig cfg;
@@ -1347,6 +1440,7 @@ extern "C" int MFCCWapperList(const char *iniPath)
     int rc = MFCCConfigFromIni(iniPath, &cfg, &bad);
     if (rc) return rc;
     const bool quiet = getenv("MFCC_QUIET") != nullptr;
+    const bool timing = getenv("MFCC_LIST_TIMING") != nullptr;
     if (!quiet) printf("finish reading the config.ini\n"); /* main.c:140 */
     MFCCContext *c = nullptr;
     if ((rc = cached_context(cfg, &c))) return rc;
@@ -1375,52 +1469,170 @@ extern "C" int MFCCWapperList(const char *iniPath)
     }
     fclose(fl);
 
-    int failed = 0;
-    const size_t kBatchBytes = (size_t)1 << 30;
-    size_t i = 0;
-    while (i < items.size()) {
-        // read files until the batch is full or the PCM layout changes
-        size_t b = i, bytes = 0;
-        int ch = 0, bps = 0;
-        while (i < items.size()) {
-            ListItem &it = items[i];
-            if (it.status == MFCC_OK && it.file.empty()) {
-                if (!quiet) printf("Convert %s to %s\n", it.src.c_str(), it.dst.c_str()); /* main.c:180 */
-                int r = read_file(it.src.c_str(), it.file);
-                if (!r) r = wav_parse(it.file.data(), it.file.size(), it.w);
-                if (!r && cfg.sampleRate != it.w.sampleRate) {
-                    set_error("Sample rate not right (config %d, file %d)", cfg.sampleRate, it.w.sampleRate);
-                    r = MFCC_E_SAMPLE_RATE;
+    const int nth = std::max(1, cfg.numThreads);
+    const size_t el = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
+    const size_t kBatchPcm = (size_t)64 << 20, kBatchOut = (size_t)256 << 20, kBatchFiles = 4096;
+    constexpr int kSlots = 3;
+    ListBatch slots[kSlots];
+    BlockingQueue<ListBatch *> freeQ, loadedQ, computedQ;
+    for (auto &sl : slots) freeQ.push(&sl);
+    double tRead = 0, tPack = 0, tDev = 0, tWrite = 0;
+
+    std::thread devThread([&]() {
+        GrowDevBuf dPcm, dOut;
+        hipStream_t st = nullptr;
+        bool ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreate(&st) == hipSuccess;
+        for (;;) {
+            ListBatch *b = loadedQ.pop();
+            if (!b) break;
+            const double t0 = now_s();
+            if (!ok) {
+                set_error("no HIP device available (the library has no CPU path)");
+                b->rc = MFCC_E_DEVICE;
+            } else {
+                b->rc = list_device_stage(c, *b, dPcm, dOut, st);
+            }
+            if (b->rc) b->message = MFCCLastError();
+            tDev += now_s() - t0;
+            computedQ.push(b);
+        }
+        if (st) (void)hipStreamDestroy(st);
+        computedQ.push(nullptr);
+    });
+
+    std::thread writeThread([&]() {
+        for (;;) {
+            ListBatch *b = computedQ.pop();
+            if (!b) break;
+            const double t0 = now_s();
+            if (b->rc) {
+                for (size_t i : b->idx) {
+                    items[i].status = b->rc;
+                    items[i].message = b->message;
                 }
-                if (r) {
-                    it.status = r;
-                    it.message = MFCCLastError();
-                    it.file.clear();
+            } else {
+                parallel_for(b->idx.size(), nth, [&](size_t u) {
+                    ListItem &it = items[b->idx[u]];
+                    const size_t n = (size_t)b->frames[u] * c->step;
+                    const size_t first = (size_t)b->rowOff[u] * c->step;
+                    int wrc;
+                    if (el == 8) {
+                        wrc = MFCCWriteFeatures(it.dst.c_str(), static_cast<const double *>(b->hOut.p) + first,
+                                                (long)b->frames[u], c->step, cfg.saveType);
+                    } else {
+                        std::vector<double> rows(std::max<size_t>(n, 1));
+                        const float *src = static_cast<const float *>(b->hOut.p) + first;
+                        for (size_t k = 0; k < n; ++k) rows[k] = (double)src[k];
+                        wrc = MFCCWriteFeatures(it.dst.c_str(), rows.data(), (long)b->frames[u], c->step,
+                                                cfg.saveType);
+                    }
+                    if (wrc) {
+                        it.status = wrc;
+                        it.message = MFCCLastError();
+                    }
+                });
+            }
+            tWrite += now_s() - t0;
+            freeQ.push(b);
+        }
+    });
+
+    // stage 1 on the calling thread
+    size_t cursor = 0;
+    while (cursor < items.size()) {
+        ListBatch *b = freeQ.pop();
+        b->idx.clear(), b->off.clear(), b->ns.clear();
+        b->rc = MFCC_OK, b->message.clear(), b->pcmBytes = 0;
+        // candidates: enough files (by size on disk) for one batch
+        double t0 = now_s();
+        size_t end = cursor, bytes = 0;
+        while (end < items.size() && bytes < kBatchPcm && end - cursor < kBatchFiles) {
+            ListItem &it = items[end];
+            if (it.status == MFCC_OK) {
+                if (!quiet && !it.announced) /* main.c:180 */
+                    printf("Convert %s to %s\n", it.src.c_str(), it.dst.c_str());
+                it.announced = true;
+                if (!it.file.empty()) {
+                    bytes += it.file.size();
+                } else {
+                    FILE *fp = fopen(it.src.c_str(), "rb");
+                    if (fp) {
+                        fseek(fp, 0, SEEK_END);
+                        const long sz = ftell(fp);
+                        fclose(fp);
+                        bytes += sz > 0 ? (size_t)sz : 0;
+                    }
                 }
             }
-            if (it.status != MFCC_OK) { // a failed file closes the batch; it is skipped
-                ++i;
+            ++end;
+        }
+        parallel_for(end - cursor, nth, [&](size_t k) {
+            ListItem &it = items[cursor + k];
+            if (it.status != MFCC_OK || !it.file.empty()) return;
+            int r = read_file(it.src.c_str(), it.file);
+            if (!r) r = wav_parse(it.file.data(), it.file.size(), it.w);
+            if (!r && cfg.sampleRate != it.w.sampleRate) { /* main.c:192-196 */
+                set_error("Sample rate not right (config %d, file %d)", cfg.sampleRate, it.w.sampleRate);
+                r = MFCC_E_SAMPLE_RATE;
+            }
+            if (r) {
+                it.status = r;
+                it.message = MFCCLastError();
+                std::vector<unsigned char>().swap(it.file);
+            }
+        });
+        tRead += now_s() - t0;
+        t0 = now_s();
+        // the batch: the leading run of readable files with one PCM layout; files behind a layout
+        // change stay loaded for the next batch
+        size_t outBytes = 0, i = cursor;
+        for (; i < end; ++i) {
+            ListItem &it = items[i];
+            if (it.status != MFCC_OK) continue;
+            if (b->idx.empty()) {
+                b->channels = it.w.channels;
+                b->bps = it.w.bytesPerSample;
+            } else if (b->channels != it.w.channels || b->bps != it.w.bytesPerSample ||
+                       outBytes >= kBatchOut) {
                 break;
             }
-            if (ch == 0) {
-                ch = it.w.channels;
-                bps = it.w.bytesPerSample;
-            } else if (ch != it.w.channels || bps != it.w.bytesPerSample) {
-                break; // leave it for the next batch (it is re-read there)
-            }
-            bytes += it.file.size();
-            ++i;
-            if (bytes >= kBatchBytes) break;
+            b->idx.push_back(i);
+            b->off.push_back((int64_t)b->pcmBytes);
+            b->ns.push_back(it.w.numSamples);
+            b->pcmBytes += ((size_t)it.w.numSamples * b->channels * b->bps + 15) & ~(size_t)15;
+            outBytes += (size_t)MFCCNumFrames(it.w.numSamples, cfg.wlen, cfg.inc) * c->step * el;
         }
-        // [b, e) holds the readable files of this batch (the last one may be the failed one)
-        size_t e = i;
-        while (e > b && items[e - 1].status != MFCC_OK) --e;
-        if (e > b) run_group(c, cfg, items, b, e);
-        for (size_t k = b; k < i; ++k) {
-            items[k].file.clear();
-            items[k].file.shrink_to_fit();
+        cursor = i;
+        if (b->idx.empty()) {
+            freeQ.push(b);
+            continue;
         }
+        int prc = b->hPcm.ensure(std::max<size_t>(b->pcmBytes, 16));
+        if (prc) {
+            b->rc = prc;
+            b->message = MFCCLastError();
+        } else {
+            parallel_for(b->idx.size(), nth, [&](size_t u) {
+                ListItem &it = items[b->idx[u]];
+                memcpy(static_cast<unsigned char *>(b->hPcm.p) + b->off[u], it.file.data() + it.w.dataOffset,
+                       (size_t)it.w.numSamples * b->channels * b->bps);
+                std::vector<unsigned char>().swap(it.file);
+            });
+        }
+        tPack += now_s() - t0;
+        if (b->rc)
+            computedQ.push(b); // straight to the stage that records the failure
+        else
+            loadedQ.push(b);
     }
+    loadedQ.push(nullptr);
+    devThread.join();
+    writeThread.join();
+    if (timing)
+        fprintf(stderr, "MFCCWapperList stages (busy seconds): read %.3f pack %.3f device %.3f write %.3f\n",
+                tRead, tPack, tDev, tWrite);
+
+    int failed = 0;
     for (const ListItem &it : items)
         if (it.status != MFCC_OK) {
             ++failed;

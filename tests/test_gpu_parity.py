@@ -295,6 +295,53 @@ def test_wapper_entry_points_and_writers(oracle, tmp_path):
     assert not (tmp_path / "nope.txt").exists()
 
 
+def test_wapper_list_batches_mixed_layouts(oracle, tmp_path):
+    """The whole-run entry point over a list whose PCM layout changes back and forth (every change
+    closes a batch and carries the files already read over to the next one), with a missing file
+    and a file shorter than one frame in between: every output equals the per-file entry point's."""
+    kw = dict(CONFIGS["c3"], vecNum=1)
+    cfg = ma.make_config(saveType=ma.SAVE_B, **kw)
+    layouts = [(1, 2), (1, 2), (2, 3), (1, 2), (2, 2), (2, 2), (1, 3), (1, 2)]
+    lines, expect = [], {}
+    for i in range(40):
+        ch, bps = layouts[i % len(layouts)]
+        n = 100 if i == 13 else 3000 + 517 * i
+        pcm = _pcm(n, ch, bps, 100 + i, 16000)
+        wav = tmp_path / ("f%02d.wav" % i)
+        wav.write_bytes(ma.wav_bytes(pcm, ch, bps, 16000))
+        if i == 7:
+            wav = tmp_path / "missing.wav"
+        lines.append("%s\t%s" % (wav, tmp_path / ("f%02d.bin" % i)))
+        if i != 7:
+            expect[i] = (pcm, ch, bps)
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(lines) + "\n")
+    ini = tmp_path / "config.ini"
+    sections = {"Frame": ["sampleRate", "hipassfre", "lowpassfre", "preemphasise", "wlen", "inc", "vecNum",
+                          "zeroMeanSigFlag"],
+                "MFCC": ["fbankFlag", "bankNum", "MFCCNum", "MFCC0thFlag"],
+                "Others": ["energyFlag", "zeroCrossingFlag", "brightFlag", "subBandEFlag", "fftLength"],
+                "Regression": ["regreOrder", "delwin", "znormFlag"]}
+    text = ""
+    for sec, keys in sections.items():
+        text += "[%s]\n" % sec + "".join("%s = %s\n" % (k, kw[k]) for k in keys if k in kw)
+    assert sum(k in kw for keys in sections.values() for k in keys) == len(kw)
+    ini.write_text(text + "[IO]\nsaveType = b\nnumThreads = 3\nfileList = %s\n" % lst)
+    os.environ["MFCC_QUIET"] = "1"
+    assert ma.wapper_list(str(ini)) == 1
+    assert not (tmp_path / "f07.bin").exists()
+    step = ma.step(cfg)
+    for i, (pcm, ch, bps) in expect.items():
+        got = np.fromfile(tmp_path / ("f%02d.bin" % i), dtype=np.float64).reshape(-1, step)
+        want = ma.wapper_mem(cfg, ma.wav_bytes(pcm, ch, bps, 16000))
+        assert got.shape == want.shape, i
+        assert np.array_equal(got, want, equal_nan=True), i
+    assert (tmp_path / "f13.bin").stat().st_size == 0  # shorter than one frame: no rows
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), expect[2][0], 2, 3)
+    got = np.fromfile(tmp_path / "f02.bin", dtype=np.float64).reshape(-1, step)
+    _compare(got, ref, kw, False)
+
+
 @pytest.mark.parametrize("name,n,ch,bps", [("c5", 60000, 2, 3), ("c3", 20000, 1, 2)])
 def test_frame_sharded_recording_matches_whole(oracle, name, n, ch, bps):
     """Shard plans (halo frames, lead instant, split z-norm) for 3 ranks emulated on one GPU."""
