@@ -31,6 +31,28 @@ using namespace mfcc;
         }                                                                                   \
     } while (0)
 
+// Makes `device` current for the enclosing scope and restores the caller's device afterwards: a
+// library call must not leave the calling thread on another GPU.
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device);
+        else prev = -1; // nothing to restore
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define DEVICE_SCOPE(dev)            \
+    DeviceScope deviceScope_(dev);   \
+    HIP_TRY(deviceScope_.err)
+
 // ------------------------------------------------------------------------------------------
 
 struct MFCCContext {
@@ -109,8 +131,8 @@ extern "C" int MFCCContextCreate(const MFCCConfig *cfgIn, int device, MFCCContex
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return set_error("no HIP device available (the library has no CPU path)"), MFCC_E_DEVICE;
     if (device < 0 || device >= ndev) return set_error("device %d out of range", device), MFCC_E_DEVICE;
-    HIP_TRY(hipSetDevice(device));
-    std::unique_ptr<MFCCContext> c(new MFCCContext);
+    DEVICE_SCOPE(device);
+    std::unique_ptr<MFCCContext, void (*)(MFCCContext *)> c(new MFCCContext, MFCCContextDestroy);
     c->cfg = cfg;
     c->device = device;
     rc = build_tables(cfg, c->tab);
@@ -154,7 +176,7 @@ extern "C" int MFCCContextCreate(const MFCCConfig *cfgIn, int device, MFCCContex
 extern "C" void MFCCContextDestroy(MFCCContext *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceScope scope(c->device);
     (void)hipFree(c->dWindow);
     (void)hipFree(c->dTw);
     (void)hipFree(c->dSplitTw);
@@ -571,7 +593,7 @@ static int finish_plan(MFCCPlan *p)
     p->numRegBlocks = (int)regBlocks;
     p->numTiles = (int)tiles;
     p->numChunks = (int)chunks;
-    HIP_TRY(hipSetDevice(c->device));
+    DEVICE_SCOPE(c->device);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0)
@@ -753,7 +775,7 @@ extern "C" int MFCCPlanCreateShard(MFCCContext *c, int channels, int bytesPerSam
 extern "C" void MFCCPlanDestroy(MFCCPlan *p)
 {
     if (!p) return;
-    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    DeviceScope scope(p->ctx ? p->ctx->device : 0);
     (void)hipFree(p->dUtts);
     (void)hipFree(p->dTileUtt);
     (void)hipFree(p->dTiles);
@@ -790,7 +812,7 @@ extern "C" int MFCCPlanEnableTiming(MFCCPlan *p, int on)
 {
     if (!p) return set_error("NULL plan"), MFCC_E_ARG;
     if (on && !p->evStart) {
-        HIP_TRY(hipSetDevice(p->ctx->device));
+        DEVICE_SCOPE(p->ctx->device);
         HIP_TRY(hipEventCreate(&p->evStart));
         HIP_TRY(hipEventCreate(&p->evStop));
     }
@@ -1003,7 +1025,7 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
     for (const UttDesc &d : p->utts) // every planned byte must lie inside the caller's buffer
         if (d.numFrames > 0 && (uint64_t)(d.byteOff + (int64_t)d.numInstants * bpi) > (uint64_t)pcmBytes)
             return set_error("PCM buffer of %zu bytes is shorter than the plan needs", pcmBytes), MFCC_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    DEVICE_SCOPE(c->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
     if (c->cfg.zeroMeanSigFlag && !p->shard) {
@@ -1047,7 +1069,7 @@ extern "C" int MFCCShardColumnSums(MFCCContext *c, MFCCPlan *p, const void *outD
 {
     if (!c || !p || p->ctx != c || !p->shard || !sumsDev) return set_error("bad argument"), MFCC_E_ARG;
     if (!c->cfg.znormFlag) return set_error("znormFlag is off"), MFCC_E_CONFIG;
-    HIP_TRY(hipSetDevice(c->device));
+    DEVICE_SCOPE(c->device);
     if (p->numChunks == 0) {
         HIP_TRY(hipMemsetAsync(sumsDev, 0, (size_t)(2 * c->step + 1) * sizeof(double), static_cast<hipStream_t>(stream)));
         return MFCC_OK;
@@ -1067,7 +1089,7 @@ extern "C" int MFCCShardNormalize(MFCCContext *c, MFCCPlan *p, void *outDev, con
     if (!c || !p || p->ctx != c || !p->shard || !sumsDev) return set_error("bad argument"), MFCC_E_ARG;
     if (p->numChunks == 0) return MFCC_OK;
     if (!outDev) return set_error("NULL device buffer"), MFCC_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    DEVICE_SCOPE(c->device);
     return run_normalize(c, p, outDev, true, sumsDev, stream);
 }
 
@@ -1077,7 +1099,7 @@ extern "C" int MFCCChannelSums(MFCCContext *c, const void *pcmDev, int channels,
     if (!c || !sums2Dev || (count > 0 && !pcmDev)) return set_error("bad argument"), MFCC_E_ARG;
     if (channels < 1 || channels > 2 || bytesPerSample < 2 || bytesPerSample > 4)
         return set_error("unsupported PCM layout"), MFCC_E_WAV;
-    HIP_TRY(hipSetDevice(c->device));
+    DEVICE_SCOPE(c->device);
     HIP_TRY(hipMemsetAsync(sums2Dev, 0, 4 * sizeof(int64_t), static_cast<hipStream_t>(stream)));
     const int rc = launch_chansums(static_cast<const unsigned char *>(pcmDev), channels, bytesPerSample,
                                    sampleBegin * channels * bytesPerSample, count,
@@ -1115,7 +1137,7 @@ extern "C" int MFCCWave2FBankDevice(MFCCContext *c, const void *framesDev, int n
 {
     if (!c || numFrames < 0 || (numFrames > 0 && (!framesDev || !fbankDev)))
         return set_error("bad argument to MFCCWave2FBankDevice"), MFCC_E_ARG;
-    HIP_TRY(hipSetDevice(c->device));
+    DEVICE_SCOPE(c->device);
     const int rc = launch_wave2fbank_batch(c->cfg.precision == MFCC_PREC_F64, framesDev, fbankDev, teDev, numFrames,
                                            c->cfg.wlen, c->tab.fftN, c->tab.klo, c->tab.khi, c->cfg.bankNum,
                                            c->dLoChan, c->dLoWt, stream);
@@ -1129,7 +1151,7 @@ extern "C" int MFCCFBank2MFCCDevice(MFCCContext *c, const void *fbankDev, int nu
     if (!c || numFrames < 0 || (numFrames > 0 && (!fbankDev || !mfccDev)))
         return set_error("bad argument to MFCCFBank2MFCCDevice"), MFCC_E_ARG;
     if (c->cfg.fbankFlag) return set_error("the context is in filterbank mode (fbankFlag): it has no cepstral table"), MFCC_E_CONFIG;
-    HIP_TRY(hipSetDevice(c->device));
+    DEVICE_SCOPE(c->device);
     const int rc = launch_fbank2mfcc_batch(c->cfg.precision == MFCC_PREC_F64, fbankDev, mfccDev, c0Dev, numFrames,
                                            c->cfg.bankNum, c->M, c->dDct, c->dctPitch, c->tab.mfnorm, stream);
     if (rc) return set_error("FBank2MFCC kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;

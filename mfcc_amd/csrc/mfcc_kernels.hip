@@ -290,7 +290,10 @@ __device__ __forceinline__ void fft_load_twiddles(cpx<T> *twr, int l, const cpx<
                           TWR + (LOGNS > 0 ? NB * (R - 1) : 0)>(twr, l, tw);
 }
 
-template <typename T, int LOG2NC, int PPLOG, int LOGNS, int TWOFF, bool TWLDS, bool TWREG = false, int TWR = 0>
+// KEEPLAST: the last stage's results stay in the lane's registers (v[r] = point l + r G, which
+// needs a single butterfly per lane there) instead of going to the work area.
+template <typename T, int LOG2NC, int PPLOG, int LOGNS, int TWOFF, bool TWLDS, bool TWREG = false, int TWR = 0,
+          bool KEEPLAST = false>
 __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<T> *Z, int l,
                                            const cpx<T> *tw, const cpx<T> *twr = nullptr)
 {
@@ -330,6 +333,10 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) Radix<T, R>::run(&v[b * R]);
+    if constexpr (KEEPLAST && LOGNS + RB == LOG2NC) {
+        static_assert(NB == 1 && NS == G, "the last stage must be one butterfly per lane");
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = l + G * b;
@@ -340,7 +347,16 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
     group_sync<G>();
     if constexpr (LOGNS + RB < LOG2NC)
         fft_stages<T, LOG2NC, PPLOG, LOGNS + RB, TWOFF + (LOGNS > 0 ? (R - 1) * NS : 0), TWLDS, TWREG,
-                   TWR + (LOGNS > 0 ? NB * (R - 1) : 0)>(v, Z, l, tw, twr);
+                   TWR + (LOGNS > 0 ? NB * (R - 1) : 0), KEEPLAST>(v, Z, l, tw, twr);
+}
+
+// Value of x in lane (16 - l) mod 16 of the same row of 16 lanes: mirror the row, then rotate it
+// right by one (data-parallel primitives, no LDS traffic).
+__device__ __forceinline__ float row_negated_lane(float x)
+{
+    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false); // row_mirror
+    const int r = __builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, false);                          // row_ror:1
+    return __builtin_bit_cast(float, r);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -505,6 +521,12 @@ __device__ __forceinline__ void unpack_tile_fast_sel(bool exact, T *rows, const 
 
 // Diagnostic build only (-DMFCC_STAMPS): per-phase cycle shares of the static-feature kernel,
 // summed over waves into FrontArgs::stamps.  Never compiled into the shipped library.
+#ifdef MFCC_NO_REGSPLIT // A/B switch for measurements: split through the LDS work area everywhere
+constexpr bool kNoRegSplit = true;
+#else
+constexpr bool kNoRegSplit = false;
+#endif
+
 #if defined(MFCC_STAMPS) && defined(MFCC_SKIP_ONLY)
 #define STAMP_DECL
 #define STAMP_START
@@ -675,6 +697,9 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     // With 16 points per lane the kernel runs at two waves per SIMD: the 256-register budget also
     // holds the lane's twiddle factors.
     constexpr bool TWREG = LEAN && PPLOG == 4;
+    // Matrix-core mode with 16 lanes x 16 points per frame: the last FFT stage stays in registers
+    // and the real-FFT split takes its partner points from the neighbouring lane by DPP.
+    constexpr bool REGSPLIT = MELM && sizeof(T) == 4 && G == 16 && PPL == 16 && !kNoRegSplit;
     cpx<T> twr[TWREG ? fft_twiddle_regs<LOG2NC, PPLOG>() : 1];
     if constexpr (TWREG) fft_load_twiddles<T, LOG2NC, PPLOG>(twr, l, reinterpret_cast<const cpx<T> *>(tw));
 
@@ -914,14 +939,25 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 
             // ---- nc-point complex FFT of z[n] = x[2n] + i x[2n+1]   (Realft mfcc.c:262-270)
             if (!SKIP(2))
-                fft_stages<T, LOG2NC, PPLOG, 0, 0, TLDS, TWREG>(v, Z, l, reinterpret_cast<const cpx<T> *>(tw), twr);
+                fft_stages<T, LOG2NC, PPLOG, 0, 0, TLDS, TWREG, 0, REGSPLIT>(v, Z, l, reinterpret_cast<const cpx<T> *>(tw),
+                                                                          twr);
             STAMP(3);
 
             // ---- real-FFT split and power  (mfcc.c:274-290, ek of mfcc.c:153-155)
             // X[k] = E + w O, X[nc-k] = conj(E - w O), w = exp(-i pi k / nc); only |X|^2 is kept.
             T pa[NPAIR], pb[NPAIR];
             cpx<T> zas[NPAIR], zbs[NPAIR]; // Z[k] and Z[nc - k] for k = l + G q
-            if constexpr (sizeof(T) == 4 && G % 16 == 0 && PPL >= 2) {
+            if constexpr (REGSPLIT) {
+                // v[r] = Z[l + 16 r].  Z[nc - l - 16 q] is register 15 - q of lane 16 - l; for
+                // lane 0 it is the lane's own register 16 - q (q = 0 is fixed up below).
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) {
+                    zas[q] = v[q];
+                    const cpx<T> hi = v[PPL - 1 - q], own = v[(PPL - q) & (PPL - 1)];
+                    const float px = row_negated_lane((float)hi.x), py = row_negated_lane((float)hi.y);
+                    zbs[q] = {l == 0 ? own.x : (T)px, l == 0 ? own.y : (T)py};
+                }
+            } else if constexpr (sizeof(T) == 4 && G % 16 == 0 && PPL >= 2) {
                 // zpad(l + G q) = zpad(l) + q (G + G/16), zpad(nc - l - G q) = zpad(nc - l) - q (G + G/16)
                 constexpr int QS = (G + G / 16) * 8;
                 cpx<T> rev[NPAIR];
@@ -958,7 +994,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             }
             {
                 // bin 0 packs Re + Im of Z[0] (mfcc.c:288-290); bin nc/2 is |Z[nc/2]|^2
-                const cpx<T> z0 = Z[0], zh = Z[zpad(NC / 2)];
+                // (register split: lane 0, the only user, holds Z[0] and Z[nc/2] = Z[16 * 8] itself)
+                const cpx<T> z0 = REGSPLIT ? v[0] : Z[0], zh = REGSPLIT ? v[PPL / 2] : Z[zpad(NC / 2)];
                 const T p0 = (z0.x + z0.y) * (z0.x + z0.y);
                 const T ph = NC > 1 ? zh.x * zh.x + zh.y * zh.y : (T)0;
                 pa[0] = l == 0 ? p0 : pa[0];
