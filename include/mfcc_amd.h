@@ -235,6 +235,24 @@ int MFCCRealftDevice(int precision, void *dataDev, int numFrames, int n, void *s
  * log filterbank values (usePower = 1, floor 1.0) and, if teDev != NULL, the frame energies. */
 int MFCCWave2FBankDevice(MFCCContext *ctx, const void *framesDev, int numFrames, void *fbankDev,
                          void *teDev, void *stream);
+/* The same with explicit tables and every output of the reference's function: InitFBank's results
+ * for any (frameSize, sampPeriod, numChans, lopass, hipass) come from MFCCFBankTables (host, double;
+ * alpha = 1, doubleFFT = 0 as at main.c:168; entry [k-1] = the reference's [k]; loChan/loWt are
+ * uploaded by the caller), usePower / takeLogs as in FBankInfo (mfcc.c:154-157,171-176); te2Dev
+ * (mfcc.c:164-168) and specDev (numFrames x fftN: the packed spectrum the reference leaves in info.x,
+ * read by main.c:235-236) may be NULL. */
+int MFCCFBankTables(int frameSize, double sampPeriod, int numChans, double lopass, double hipass,
+                    int *fftN, int *klo, int *khi, double *fres, double *cf, int *loChan, double *loWt,
+                    char *passband, size_t cap);
+int MFCCWave2FBankTablesDevice(int precision, const void *framesDev, int numFrames, int frameSize,
+                               int fftN, int klo, int khi, int numChans, const int *loChanDev,
+                               const void *loWtDev, int usePower, int takeLogs, void *fbankDev,
+                               void *teDev, void *te2Dev, void *specDev, void *stream);
+/* FBank2MFCC / FBank2C0 for any channel count without a context: the cosines of mfcc.c:192 are
+ * evaluated in the kernel.  numFrames x numChans -> numFrames x n (and numFrames C0 values if
+ * c0Dev != NULL). */
+int MFCCFBank2MFCCDirectDevice(int precision, const void *fbankDev, int numFrames, int numChans, int n,
+                               void *mfccDev, void *c0Dev, void *stream);
 /* FBank2MFCC (mfcc.c:180-195) and, if c0Dev != NULL, FBank2C0 (mfcc.c:197-208): numFrames x bankNum
  * -> numFrames x MFCCNum values (C0: numFrames values).  The context must not be in filterbank mode. */
 int MFCCFBank2MFCCDevice(MFCCContext *ctx, const void *fbankDev, int numFrames, void *mfccDev,

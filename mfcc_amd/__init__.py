@@ -71,6 +71,7 @@ EXPORTS = [
     "MFCCExtractDevice", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
     "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm", "MFCCFormatValue",
     "MFCCFFTDevice", "MFCCRealftDevice", "MFCCWave2FBankDevice", "MFCCFBank2MFCCDevice", "MFCCMel",
+    "MFCCFBankTables", "MFCCWave2FBankTablesDevice", "MFCCFBank2MFCCDirectDevice",
 ]
 
 
@@ -143,7 +144,69 @@ def lib():
     L.MFCCFBank2MFCCDevice.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.MFCCMel.argtypes = [C.c_int, C.c_double]
     L.MFCCMel.restype = C.c_double
+    L.MFCCFBankTables.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp, C.POINTER(C.c_int), dp,
+                                  C.c_char_p, C.c_size_t]
+    L.MFCCWave2FBankTablesDevice.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                             vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.MFCCFBank2MFCCDirectDevice.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     _lib = L
+    return L
+
+
+COMPAT_LIB_PATH = os.path.join(_HERE, "libmfcc_compat.so")
+# every function include/mfcc_compat.h declares
+COMPAT_EXPORTS = ["Mel", "InitFBank", "Wave2FBank", "FBank2MFCC", "FBank2C0", "FFT", "Realft",
+                  "MFCCCreateVector", "MFCCCreateIntVec", "MFCCVectorSize", "MFCCFreeVector", "MFCCFreeFBank",
+                  "MFCCCompatStatus"]
+
+
+class FBankInfo(C.Structure):
+    """mfcc.h:14-27 as include/mfcc_compat.h declares it."""
+    _fields_ = [("frameSize", C.c_int), ("numChans", C.c_int), ("sampPeriod", C.c_double), ("fftN", C.c_int),
+                ("klo", C.c_int), ("khi", C.c_int), ("usePower", C.c_int), ("takeLogs", C.c_int),
+                ("fres", C.c_double), ("cf", C.POINTER(C.c_double)), ("loChan", C.POINTER(C.c_int)),
+                ("loWt", C.POINTER(C.c_double)), ("x", C.POINTER(C.c_double))]
+
+
+_compat = None
+
+
+def compat_lib():
+    """libmfcc_compat.so: the reference's own function names (mfcc.h:29-74) on 1-based vectors."""
+    global _compat
+    if _compat is not None:
+        return _compat
+    lib()  # the main library (and torch's HIP runtime) first
+    if not os.path.exists(COMPAT_LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C mfcc_amd/csrc`" % COMPAT_LIB_PATH)
+    L = C.CDLL(COMPAT_LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    L.Mel.argtypes = [C.c_int, C.c_double]
+    L.Mel.restype = C.c_double
+    L.InitFBank.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                            C.c_double, C.c_double, C.c_double]
+    L.InitFBank.restype = FBankInfo
+    L.Wave2FBank.argtypes = [dp, dp, dp, dp, FBankInfo]
+    L.Wave2FBank.restype = None
+    L.FBank2MFCC.argtypes = [dp, dp, C.c_int]
+    L.FBank2MFCC.restype = None
+    L.FBank2C0.argtypes = [dp]
+    L.FBank2C0.restype = C.c_double
+    L.FFT.argtypes = [dp, C.c_int]
+    L.FFT.restype = None
+    L.Realft.argtypes = [dp]
+    L.Realft.restype = None
+    L.MFCCCreateVector.argtypes = [C.c_int]
+    L.MFCCCreateVector.restype = dp
+    L.MFCCCreateIntVec.argtypes = [C.c_int]
+    L.MFCCCreateIntVec.restype = C.POINTER(C.c_int)
+    L.MFCCVectorSize.argtypes = [C.c_void_p]
+    L.MFCCFreeVector.argtypes = [C.c_void_p]
+    L.MFCCFreeVector.restype = None
+    L.MFCCFreeFBank.argtypes = [C.POINTER(FBankInfo)]
+    L.MFCCFreeFBank.restype = None
+    _compat = L
     return L
 
 

@@ -79,6 +79,11 @@ struct MFCCPlan {
     int deltaSubRows = 0, deltaRedOffset = 0; // fused delta kernel geometry (0: not used)
     size_t deltaLds = 0;
     double *dBlockPartial = nullptr;
+    // whole-utterance finishing pass (deltas + z-norm from compact static rows), see finish.hip
+    bool uttFinish = false;
+    void *dStatics = nullptr; // totalRows x vSize
+    int finSubRows = 0, finStaticElems = 0, finRedOffset = 0;
+    size_t finLds = 0;
     int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
     std::vector<float> melW;
     std::vector<int32_t> melMeta;
@@ -628,10 +633,34 @@ static int finish_plan(MFCCPlan *p)
         HIP_TRY(hipMalloc((void **)&p->dMelMeta, p->melMeta.size() * sizeof(int32_t)));
         HIP_TRY(hipMemcpy(p->dMelMeta, p->melMeta.data(), p->melMeta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    // Whole-utterance finishing pass: batch plans whose longest utterance's static rows fit the
+    // LDS budget (two workgroups per CU) beside the sub-tile buffers.
+    p->uttFinish = false;
+    if (!p->shard && c->cfg.regreOrder <= 3 && (c->cfg.regreOrder >= 2 || c->cfg.znormFlag) && c->vSize <= kBlock &&
+        p->totalRows > 0 && !getenv("MFCC_NO_UTT_FINISH")) {
+        const size_t elb = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
+        int64_t maxFrames = 1;
+        for (const UttDesc &d : p->utts) maxFrames = std::max<int64_t>(maxFrames, d.numFrames);
+        const size_t statics = (size_t)maxFrames * c->vSize;
+        for (int sr = 64; sr >= 8 && !p->uttFinish; sr /= 2) {
+            const size_t elems = statics + (size_t)(sr + 2 * c->cfg.delwin) * c->vSize + (size_t)sr * c->step;
+            const size_t redOff = (elems * elb + 15) & ~(size_t)15;
+            const size_t total = redOff + (2 * (size_t)kFinishBlock + 2 * (size_t)c->step) * sizeof(double);
+            if (total <= 80 * 1024) {
+                p->uttFinish = true;
+                p->finSubRows = sr;
+                p->finStaticElems = (int)statics;
+                p->finRedOffset = (int)redOff;
+                p->finLds = total;
+            }
+        }
+        if (p->uttFinish)
+            HIP_TRY(hipMalloc(&p->dStatics, std::max<size_t>((size_t)p->totalRows * c->vSize * elb, 16)));
+    }
     // Fused delta (+ statistics) pass: orders 2 and 3, rows of at most one workgroup of columns,
     // two LDS tiles of (subRows + 2 halo) rows within 64 KiB.
     p->deltaSubRows = 0;
-    if (c->cfg.regreOrder >= 2 && c->vSize <= kBlock && !getenv("MFCC_NO_FUSED_DELTA")) {
+    if (!p->uttFinish && c->cfg.regreOrder >= 2 && c->vSize <= kBlock && !getenv("MFCC_NO_FUSED_DELTA")) {
         const size_t elb = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
         const int halo = (std::min(c->cfg.regreOrder, 3) - 1) * c->cfg.delwin;
         for (int sr = 256; sr >= 8 && !p->deltaSubRows; sr /= 2) {
@@ -645,7 +674,7 @@ static int finish_plan(MFCCPlan *p)
     }
     if (p->deltaSubRows && c->cfg.znormFlag && !p->shard && c->cfg.regreOrder <= 3) // sums of every column
         HIP_TRY(hipMalloc((void **)&p->dBlockPartial, std::max<size_t>(regUtt.size(), 1) * 2 * c->step * sizeof(double)));
-    const bool needStats = c->cfg.znormFlag != 0;
+    const bool needStats = c->cfg.znormFlag != 0 && !p->uttFinish;
     if (needStats) {
         HIP_TRY(hipMalloc((void **)&p->dChunkUtt, std::max<size_t>(chunkUtt.size(), 1) * sizeof(int32_t)));
         if (!chunkUtt.empty())
@@ -782,6 +811,7 @@ extern "C" void MFCCPlanDestroy(MFCCPlan *p)
     (void)hipFree(p->dRegUtt);
     (void)hipFree(p->dMelW);
     (void)hipFree(p->dBlockPartial);
+    (void)hipFree(p->dStatics);
     (void)hipFree(p->dMelMeta);
     (void)hipFree(p->dChunkUtt);
     (void)hipFree(p->dLaneSeg);
@@ -835,7 +865,7 @@ extern "C" float MFCCPlanLastKernelMs(MFCCPlan *p)
 // ------------------------------------------------------------------------------------------
 
 template <typename T>
-static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outDev, void *stream)
+static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outDev, int outStep, void *stream)
 {
     FrontArgs<T> a;
     memset(&a, 0, sizeof a);
@@ -860,7 +890,7 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.M = c->M;
     a.D = c->D;
     a.vSize = c->vSize;
-    a.step = c->step;
+    a.step = outStep; // row pitch of outDev: the full row, or vSize for the compact static buffer
     a.c0Flag = c->c0;
     a.energyFlag = c->cfg.energyFlag;
     a.zcFlag = c->cfg.zeroCrossingFlag;
@@ -972,6 +1002,29 @@ static int run_delta(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
 }
 
 template <typename T>
+static int run_finish(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
+{
+    double sigmaT2 = 0.0;
+    for (int t = 1; t <= c->cfg.delwin; ++t) sigmaT2 += (double)t * t;
+    FinishArgs<T> a;
+    memset(&a, 0, sizeof a);
+    a.statics = static_cast<const T *>(p->dStatics);
+    a.out = static_cast<T *>(outDev);
+    a.utts = p->dUtts;
+    a.vSize = c->vSize;
+    a.step = c->step;
+    a.delwin = c->cfg.delwin;
+    a.subRows = p->finSubRows;
+    a.staticElems = p->finStaticElems;
+    a.redOffset = p->finRedOffset;
+    a.znorm = c->cfg.znormFlag ? 1 : 0;
+    a.sigmaT2 = 2.0 * sigmaT2;
+    const int rc = launch_utt_finish(c->cfg.precision, &a, c->cfg.regreOrder, p->numUtts, p->finLds, stream);
+    if (rc) return set_error("finishing kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+template <typename T>
 static StatArgs<T> stat_args(MFCCContext *c, MFCCPlan *p, void *outDev)
 {
     StatArgs<T> a;
@@ -1040,12 +1093,16 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
     if (c->cfg.regreOrder > 3)
         HIP_TRY(hipMemsetAsync(outDev, 0, (size_t)p->totalRows * c->step * (f64 ? 8 : 4), st));
     if (p->timing) HIP_TRY(hipEventRecord(p->evStart, st));
-    rc = f64 ? run_front<double>(c, p, pcmDev, outDev, stream) : run_front<float>(c, p, pcmDev, outDev, stream);
+    void *frontOut = p->uttFinish ? p->dStatics : outDev;
+    const int frontStep = p->uttFinish ? c->vSize : c->step;
+    rc = f64 ? run_front<double>(c, p, pcmDev, frontOut, frontStep, stream)
+             : run_front<float>(c, p, pcmDev, frontOut, frontStep, stream);
     if (rc) return rc;
     if (p->timing) {
         HIP_TRY(hipEventRecord(p->evStop, st));
         p->timed = true;
     }
+    if (p->uttFinish) return f64 ? run_finish<double>(c, p, outDev, stream) : run_finish<float>(c, p, outDev, stream);
     const bool fused = p->deltaSubRows > 0;
     if (fused)
         rc = f64 ? run_delta<double>(c, p, outDev, stream) : run_delta<float>(c, p, outDev, stream);
@@ -1138,9 +1195,9 @@ extern "C" int MFCCWave2FBankDevice(MFCCContext *c, const void *framesDev, int n
     if (!c || numFrames < 0 || (numFrames > 0 && (!framesDev || !fbankDev)))
         return set_error("bad argument to MFCCWave2FBankDevice"), MFCC_E_ARG;
     DEVICE_SCOPE(c->device);
-    const int rc = launch_wave2fbank_batch(c->cfg.precision == MFCC_PREC_F64, framesDev, fbankDev, teDev, numFrames,
-                                           c->cfg.wlen, c->tab.fftN, c->tab.klo, c->tab.khi, c->cfg.bankNum,
-                                           c->dLoChan, c->dLoWt, stream);
+    const int rc = launch_wave2fbank_batch(c->cfg.precision == MFCC_PREC_F64, framesDev, fbankDev, teDev, nullptr,
+                                           nullptr, numFrames, c->cfg.wlen, c->tab.fftN, c->tab.klo, c->tab.khi,
+                                           c->cfg.bankNum, c->dLoChan, c->dLoWt, 1, 1, stream);
     if (rc) return set_error("Wave2FBank kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;
 }
@@ -1154,6 +1211,53 @@ extern "C" int MFCCFBank2MFCCDevice(MFCCContext *c, const void *fbankDev, int nu
     DEVICE_SCOPE(c->device);
     const int rc = launch_fbank2mfcc_batch(c->cfg.precision == MFCC_PREC_F64, fbankDev, mfccDev, c0Dev, numFrames,
                                            c->cfg.bankNum, c->M, c->dDct, c->dctPitch, c->tab.mfnorm, stream);
+    if (rc) return set_error("FBank2MFCC kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+extern "C" int MFCCFBankTables(int frameSize, double sampPeriod, int numChans, double lopass, double hipass,
+                               int *fftN, int *klo, int *khi, double *fres, double *cf, int *loChan, double *loWt,
+                               char *passband, size_t cap)
+{
+    if (frameSize < 1 || numChans < 1 || !(sampPeriod > 0.0))
+        return set_error("bad argument to MFCCFBankTables"), MFCC_E_ARG;
+    Tables t;
+    build_fbank(frameSize, sampPeriod, numChans, lopass, hipass, t);
+    if (fftN) *fftN = t.fftN;
+    if (klo) *klo = t.klo;
+    if (khi) *khi = t.khi;
+    if (fres) *fres = t.fres;
+    if (cf) std::copy(t.cf.begin(), t.cf.end(), cf);
+    if (loChan) std::copy(t.loChan.begin(), t.loChan.end(), loChan);
+    if (loWt) std::copy(t.loWt.begin(), t.loWt.end(), loWt);
+    if (passband)
+        snprintf(passband, cap, "FFT passband %d to %d out of 1 to %d\nMel passband %f to %f\n", t.klo, t.khi, t.nc,
+                 t.mlo, t.mhi); /* mfcc.c:74-75 */
+    return MFCC_OK;
+}
+
+extern "C" int MFCCWave2FBankTablesDevice(int precision, const void *framesDev, int numFrames, int frameSize,
+                                          int fftN, int klo, int khi, int numChans, const int *loChanDev,
+                                          const void *loWtDev, int usePower, int takeLogs, void *fbankDev,
+                                          void *teDev, void *te2Dev, void *specDev, void *stream)
+{
+    if (numFrames < 0 || (numFrames > 0 && (!framesDev || !fbankDev)) || !loChanDev || !loWtDev || numChans < 1 ||
+        frameSize < 1 || frameSize > fftN || !pow2_between(fftN, 4, 2 << kMaxLog2Nc) || klo < 1 || khi > fftN / 2)
+        return set_error("bad argument to MFCCWave2FBankTablesDevice"), MFCC_E_ARG;
+    const int rc = launch_wave2fbank_batch(precision == MFCC_PREC_F64, framesDev, fbankDev, teDev, te2Dev, specDev,
+                                           numFrames, frameSize, fftN, klo, khi, numChans, loChanDev, loWtDev,
+                                           usePower ? 1 : 0, takeLogs ? 1 : 0, stream);
+    if (rc) return set_error("Wave2FBank kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
+
+extern "C" int MFCCFBank2MFCCDirectDevice(int precision, const void *fbankDev, int numFrames, int numChans, int n,
+                                          void *mfccDev, void *c0Dev, void *stream)
+{
+    if (numFrames < 0 || numChans < 1 || n < 0 || (numFrames > 0 && (!fbankDev || (n > 0 && !mfccDev))))
+        return set_error("bad argument to MFCCFBank2MFCCDirectDevice"), MFCC_E_ARG;
+    const int rc = launch_fbank2mfcc_direct(precision == MFCC_PREC_F64, fbankDev, mfccDev, c0Dev, numFrames, numChans,
+                                            n, stream);
     if (rc) return set_error("FBank2MFCC kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;
 }

@@ -109,6 +109,21 @@ struct DeltaArgs {
     double *partial;         // numBlocks x 2*step: per-block column sums and sums of squares, or NULL
 };
 
+// Whole-utterance finishing pass (finish.hip)
+constexpr int kFinishBlock = 512; // threads per workgroup (one workgroup per utterance)
+template <typename T>
+struct FinishArgs {
+    const T *statics;   // totalRows x vSize, compact
+    T *out;             // totalRows x step
+    const UttDesc *utts;
+    int vSize, step, delwin;
+    int subRows;        // rows finished per round
+    int staticElems;    // elements reserved in LDS for the longest utterance's static rows
+    int redOffset;      // byte offset of the reduction scratch (2 kFinishBlock + 2 step doubles) in LDS
+    int znorm;
+    double sigmaT2;
+};
+
 template <typename T>
 struct StatArgs {
     T *data;
@@ -133,13 +148,16 @@ int launch_colstats(int precision, const void *args, int numChunks, void *stream
 int launch_colfinal(const StatArgs<float> &a, int numUtts, bool byBlock, void *stream);
 int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, double *sumsOut, void *stream);
 int launch_delta(int precision, const void *args, int orders, size_t ldsBytes, void *stream); // -2: no such variant
+int launch_utt_finish(int precision, const void *args, int orders, int numUtts, size_t ldsBytes, void *stream);
 int launch_normalize(int precision, const void *args, int numChunks, bool shardSums,
                      const double *sums, void *stream);
 // batched pieces of the reference's lower-level API (pieces.hip)
 int launch_fft_batch(int precision, void *data, int numFrames, int n, int invert, int realft, void *stream);
-int launch_wave2fbank_batch(int precision, const void *frames, void *fbank, void *te, int numFrames,
-                            int frameSize, int fftN, int klo, int khi, int P, const int *loChan,
-                            const void *loWt, void *stream);
+int launch_wave2fbank_batch(int precision, const void *frames, void *fbank, void *te, void *te2, void *spec,
+                            int numFrames, int frameSize, int fftN, int klo, int khi, int P, const int *loChan,
+                            const void *loWt, int usePower, int takeLogs, void *stream);
+int launch_fbank2mfcc_direct(int precision, const void *fbank, void *mfcc, void *c0, int numFrames, int P, int n,
+                             void *stream);
 int launch_fbank2mfcc_batch(int precision, const void *fbank, void *mfcc, void *c0, int numFrames, int P,
                             int M, const void *dctT, int dctPitch, double mfnorm, void *stream);
 int launch_chansums(const unsigned char *pcm, int channels, int bps, int64_t firstByte,

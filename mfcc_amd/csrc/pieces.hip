@@ -98,12 +98,14 @@ __global__ __launch_bounds__(kBlock) void k_fft_batch(T *data, int n, int invert
     for (int i = threadIdx.x; i < n; i += kBlock) frame[i] = s[i];
 }
 
-// mfcc.c:125-177: te, zero padding, Realft, power, two-tap mel weighting summed per channel in
-// bin order, log(max(., 1)).
+// mfcc.c:125-177: te, zero padding, Realft, power (or magnitude), two-tap mel weighting summed per
+// channel in bin order, log(max(., 1)) if takeLogs.  Optional extras the reference leaves behind for
+// its caller: the packed spectrum (info.x, read by main.c:235-236) and te2 (mfcc.c:164-168).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_wave2fbank_batch(const T *frames, T *fbank, T *te, int frameSize,
-                                                             int fftN, int klo, int khi, int P,
-                                                             const int *loChan, const T *loWt)
+__global__ __launch_bounds__(kBlock) void k_wave2fbank_batch(const T *frames, T *fbank, T *te, T *te2, T *spec,
+                                                             int frameSize, int fftN, int klo, int khi, int P,
+                                                             const int *loChan, const T *loWt, int usePower,
+                                                             int takeLogs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     T *s = reinterpret_cast<T *>(psm);
@@ -116,29 +118,42 @@ __global__ __launch_bounds__(kBlock) void k_wave2fbank_batch(const T *frames, T 
         s[i] = v;
         e += v * v;
     }
-    if (te) { // tree order differs from the reference's running sum only in the last bits
-        red[tid] = e;
+    auto block_sum = [&](T v) { // tree order differs from the reference's running sum only in the last bits
+        __syncthreads();
+        red[tid] = v;
         __syncthreads();
         for (int o = kBlock / 2; o > 0; o >>= 1) {
             if (tid < o) red[tid] += red[tid + o];
             __syncthreads();
         }
-        if (tid == 0) te[blockIdx.x] = red[0];
+        return red[0];
+    };
+    if (te) {
+        const T tot = block_sum(e);
+        if (tid == 0) te[blockIdx.x] = tot;
     }
     realft_lds(s, fftN);
+    if (spec)
+        for (int i = tid; i < fftN; i += kBlock) spec[(size_t)blockIdx.x * fftN + i] = s[i];
     // power of bin k (1-based) parked at s[k-1]: every value is read before any is written
     constexpr int kPer = (1 << kMaxLog2Nc) / kBlock;
     T ek[kPer];
+    T e2 = 0;
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int k0 = tid + j * kBlock;
         ek[j] = k0 < nc ? s[2 * k0] * s[2 * k0] + s[2 * k0 + 1] * s[2 * k0 + 1] : (T)0;
+        e2 += ek[j];
+    }
+    if (te2) {
+        const T tot = block_sum(e2);
+        if (tid == 0) te2[blockIdx.x] = tot;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int k0 = tid + j * kBlock;
-        if (k0 < nc) s[k0] = ek[j];
+        if (k0 < nc) s[k0] = usePower ? ek[j] : sqrt(ek[j]); // mfcc.c:154-157
     }
     __syncthreads();
     for (int ch = tid; ch < P; ch += kBlock) { // channel ch (0-based) = reference channel ch + 1
@@ -149,7 +164,28 @@ __global__ __launch_bounds__(kBlock) void k_wave2fbank_batch(const T *frames, T 
             if (bin == ch + 1) acc += t1;
             if (bin == ch) acc += p - t1;
         }
-        fbank[(size_t)blockIdx.x * P + ch] = log(acc < (T)1 ? (T)1 : acc);
+        fbank[(size_t)blockIdx.x * P + ch] = takeLogs ? log(acc < (T)1 ? (T)1 : acc) : acc;
+    }
+}
+
+// FBank2MFCC / FBank2C0 without a table: the cos() per product of mfcc.c:192, for any channel
+// count (one lane per coefficient, products in the reference's order).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fbank2mfcc_direct(const T *fbank, T *mfcc, T *c0, int P, int n)
+{
+    const T *fb = fbank + (size_t)blockIdx.x * P;
+    const double mfnorm = sqrt(2.0 / (double)P), piFactor = kPi / (double)P;
+    for (int j = threadIdx.x; j < n + (c0 ? 1 : 0); j += kBlock) {
+        if (j < n) {
+            const double x = (double)(j + 1) * piFactor;
+            T acc = 0;
+            for (int k = 1; k <= P; ++k) acc += fb[k - 1] * (T)cos(x * (k - 0.5));
+            mfcc[(size_t)blockIdx.x * n + j] = acc * (T)mfnorm;
+        } else {
+            T acc = 0;
+            for (int k = 0; k < P; ++k) acc += fb[k];
+            c0[blockIdx.x] = acc * (T)mfnorm;
+        }
     }
 }
 
@@ -198,9 +234,9 @@ int launch_fft_batch(int precision, void *data, int numFrames, int n, int invert
     return (int)hipGetLastError();
 }
 
-int launch_wave2fbank_batch(int precision, const void *frames, void *fbank, void *te, int numFrames,
-                            int frameSize, int fftN, int klo, int khi, int P, const int *loChan,
-                            const void *loWt, void *stream)
+int launch_wave2fbank_batch(int precision, const void *frames, void *fbank, void *te, void *te2, void *spec,
+                            int numFrames, int frameSize, int fftN, int klo, int khi, int P, const int *loChan,
+                            const void *loWt, int usePower, int takeLogs, void *stream)
 {
     if (numFrames <= 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -209,15 +245,33 @@ int launch_wave2fbank_batch(int precision, const void *frames, void *fbank, void
         if (int e = allow_lds(k_wave2fbank_batch<double>, lds)) return e;
         hipLaunchKernelGGL(k_wave2fbank_batch<double>, dim3(numFrames), dim3(kBlock), lds, st,
                            static_cast<const double *>(frames), static_cast<double *>(fbank),
-                           static_cast<double *>(te), frameSize, fftN, klo, khi, P, loChan,
-                           static_cast<const double *>(loWt));
+                           static_cast<double *>(te), static_cast<double *>(te2), static_cast<double *>(spec),
+                           frameSize, fftN, klo, khi, P, loChan, static_cast<const double *>(loWt), usePower,
+                           takeLogs);
     } else {
         if (int e = allow_lds(k_wave2fbank_batch<float>, lds)) return e;
         hipLaunchKernelGGL(k_wave2fbank_batch<float>, dim3(numFrames), dim3(kBlock), lds, st,
                            static_cast<const float *>(frames), static_cast<float *>(fbank),
-                           static_cast<float *>(te), frameSize, fftN, klo, khi, P, loChan,
-                           static_cast<const float *>(loWt));
+                           static_cast<float *>(te), static_cast<float *>(te2), static_cast<float *>(spec),
+                           frameSize, fftN, klo, khi, P, loChan, static_cast<const float *>(loWt), usePower,
+                           takeLogs);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_fbank2mfcc_direct(int precision, const void *fbank, void *mfcc, void *c0, int numFrames, int P, int n,
+                             void *stream)
+{
+    if (numFrames <= 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (precision == 1)
+        hipLaunchKernelGGL(k_fbank2mfcc_direct<double>, dim3(numFrames), dim3(kBlock), 0, st,
+                           static_cast<const double *>(fbank), static_cast<double *>(mfcc),
+                           static_cast<double *>(c0), P, n);
+    else
+        hipLaunchKernelGGL(k_fbank2mfcc_direct<float>, dim3(numFrames), dim3(kBlock), 0, st,
+                           static_cast<const float *>(fbank), static_cast<float *>(mfcc),
+                           static_cast<float *>(c0), P, n);
     return (int)hipGetLastError();
 }
 

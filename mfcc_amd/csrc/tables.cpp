@@ -10,12 +10,12 @@ namespace mfcc {
 
 static double mel_of_bin(int k, double fres) { return 1127 * log(1 + (k - 1) * fres); } // mfcc.c:13
 
-int build_tables(const MFCCConfig &cfg, Tables &t)
+// InitFBank (mfcc.c:39-122) for alpha == 1.0, doubleFFT == 0.
+int build_fbank(int frameSize, double sampPeriod, int numChans, double lopass, double hipass, Tables &t)
 {
-    const double sampPeriod = 1e7 / (double)cfg.sampleRate; // main.c:141
-    const int P = cfg.bankNum, maxChan = P + 1;
+    const int P = numChans, maxChan = P + 1;
     t.fftN = 2;
-    while (cfg.wlen > t.fftN) t.fftN *= 2; // mfcc.c:53-54
+    while (frameSize > t.fftN) t.fftN *= 2; // mfcc.c:53-54
     t.nc = t.fftN / 2;
     t.log2nc = 0;
     while ((1 << t.log2nc) < t.nc) ++t.log2nc;
@@ -27,14 +27,14 @@ int build_tables(const MFCCConfig &cfg, Tables &t)
     t.khi = half;
     t.mlo = 0;
     t.mhi = mel_of_bin(half + 1, t.fres);
-    if (cfg.lowpassfre >= 0.0) {
-        t.mlo = 1127 * log(1 + cfg.lowpassfre / 700.0);
-        t.klo = (int)((cfg.lowpassfre * sampPeriod * 1.0e-7 * t.fftN) + 2.5);
+    if (lopass >= 0.0) {
+        t.mlo = 1127 * log(1 + lopass / 700.0);
+        t.klo = (int)((lopass * sampPeriod * 1.0e-7 * t.fftN) + 2.5);
         if (t.klo < 2) t.klo = 2;
     }
-    if (cfg.hipassfre >= 0.0) {
-        t.mhi = 1127 * log(1 + cfg.hipassfre / 700.0);
-        t.khi = (int)((cfg.hipassfre * sampPeriod * 1.0e-7 * t.fftN) + 0.5);
+    if (hipass >= 0.0) {
+        t.mhi = 1127 * log(1 + hipass / 700.0);
+        t.khi = (int)((hipass * sampPeriod * 1.0e-7 * t.fftN) + 0.5);
         if (t.khi > half) t.khi = half;
     }
 
@@ -62,6 +62,14 @@ int build_tables(const MFCCConfig &cfg, Tables &t)
         else
             t.loWt[k - 1] = (t.cf[0] - melk) / (t.cf[0] - t.mlo);
     }
+    return MFCC_OK;
+}
+
+int build_tables(const MFCCConfig &cfg, Tables &t)
+{
+    const double sampPeriod = 1e7 / (double)cfg.sampleRate; // main.c:141
+    const int P = cfg.bankNum;
+    build_fbank(cfg.wlen, sampPeriod, P, cfg.lowpassfre, cfg.hipassfre, t);
     // Hamming window: HTK GenHamWindow, w[i] = 0.54 - 0.46 cos(2 pi (i-1) / (W-1))
     t.window.resize(cfg.wlen);
     {

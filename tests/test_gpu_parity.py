@@ -52,9 +52,14 @@ def _compare(got, ref, kw, f64):
         assert_static_close(got[:, o * vs:(o + 1) * vs], ref[:, o * vs:(o + 1) * vs], kw, f64, delta=o > 0)
 
 
+@pytest.mark.parametrize("finish", ["utterance", "blocks"])
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 @pytest.mark.parametrize("name", ["c2", "c3", "c4", "c1a", "c1b", "c5"])
-def test_named_configs_match_oracle(oracle, name, precision):
+def test_named_configs_match_oracle(oracle, name, precision, finish, monkeypatch):
+    """finish: deltas and z-norm by the whole-utterance kernel (short utterances) or by the
+    row-block kernels (what long utterances take; forced here through MFCC_NO_UTT_FINISH)."""
+    if finish == "blocks":
+        monkeypatch.setenv("MFCC_NO_UTT_FINISH", "1")
     kw = CONFIGS[name]
     ch, bps = _layout(kw)
     n = kw["sampleRate"] + 123  # ~1 s: several tiles, first (general) and later (fast) unpack paths
@@ -121,10 +126,13 @@ def test_lean_kernel_modes(oracle, wlen, bank, cepstral):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MFCC_FUZZ_SEEDS", "48"))))
-def test_random_configurations(oracle, seed):
+def test_random_configurations(oracle, seed, monkeypatch):
     """Seeded random walk over the option space (frame geometry, channel layouts, feature flags,
     delta orders and windows, z-norm, batches of ragged utterances at odd byte offsets): whichever
-    kernel mode, tile geometry and delta path the plan picks must agree with the oracle."""
+    kernel mode, tile geometry and delta path the plan picks must agree with the oracle.  Every
+    third seed takes the row-block delta / z-norm kernels instead of the whole-utterance one."""
+    if seed % 3 == 2:
+        monkeypatch.setenv("MFCC_NO_UTT_FINISH", "1")
     rng = np.random.default_rng(1000 + seed)
     sr = int(rng.choice([8000, 16000, 44100]))
     wlen = int(rng.choice([64, 200, 256, 400, 441, 512, 800, 1024, 1764, 2048]))
@@ -162,10 +170,15 @@ def test_random_configurations(oracle, seed):
                 _compare(got, ref, kw, f64)
 
 
-def test_ragged_batch_and_edge_lengths(oracle):
-    """Empty, shorter than a window, exactly one window, one sample short of two frames, long."""
+@pytest.mark.parametrize("finish", ["utterance", "blocks", "too long"])
+def test_ragged_batch_and_edge_lengths(oracle, finish, monkeypatch):
+    """Empty, shorter than a window, exactly one window, one sample short of two frames, long;
+    with the whole-utterance finishing kernel, with the row-block kernels forced, and with one
+    utterance too long for the former (which moves the whole plan to the latter)."""
+    if finish == "blocks":
+        monkeypatch.setenv("MFCC_NO_UTT_FINISH", "1")
     kw = CONFIGS["c3"]
-    lens = [0, 1, 399, 400, 559, 560, 561, 5000, 16000, 401, 33333]
+    lens = [0, 1, 399, 400, 559, 560, 561, 5000, 16000, 401, 33333] + ([400 + 160 * 2500] if finish == "too long" else [])
     pcms = [_pcm(n, 1, 2, 100 + i, 16000) for i, n in enumerate(lens)]
     cfg = ma.make_config(**kw)
     got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 1, 2)
@@ -474,3 +487,64 @@ def test_lower_level_api_pieces(oracle, precision):
     ctx.close()
     fres = 1.0e7 / (1e7 / 16000 * 512 * 700.0)
     assert abs(ma.mel(17, fres) - 1127 * np.log(1 + 16 * fres)) < 1e-12
+
+
+def test_reference_named_functions_on_one_based_vectors(oracle):
+    """InitFBank / Wave2FBank / FBank2MFCC / FBank2C0 / FFT / Realft under the reference's own names
+    and 1-based Vector convention (include/mfcc_compat.h), against the oracle's restatement of the
+    same functions: tables bit-exact, arithmetic to double rounding."""
+    import ctypes as C
+    L = ma.compat_lib()
+    rng = np.random.default_rng(9)
+
+    def vec(a):
+        v = L.MFCCCreateVector(len(a))
+        for i, x in enumerate(a):
+            v[i + 1] = float(x)
+        return v
+
+    def arr(v):
+        return np.array([v[i + 1] for i in range(L.MFCCVectorSize(v))])
+
+    for (W, sr, P, lo, hi) in [(400, 16000, 40, -1.0, -1.0), (400, 16000, 26, 64.0, 8000.0), (1764, 44100, 40, 10.0, 22050.0)]:
+        info = L.InitFBank(W, 1e7 / sr, P, lo, hi, 1, 1, 0, 1.0, 0.0, 0.0)
+        assert L.MFCCCompatStatus() == 0
+        t = oracle.fbank_tables(W, sr, P, lo, hi)
+        assert (info.fftN, info.klo, info.khi) == (t["fftN"], t["klo"], t["khi"])
+        nby2 = info.fftN // 2
+        assert np.array_equal(np.array([info.cf[i + 1] for i in range(P + 1)]), t["cf"])
+        assert np.array_equal(np.array([info.loChan[i + 1] for i in range(nby2)]), t["loChan"])
+        assert np.array_equal(np.array([info.loWt[i + 1] for i in range(nby2)]), t["loWt"])
+        for kind in ("noise", "silence", "impulse"):
+            frame = rng.standard_normal(W) * 4000.0 if kind == "noise" else np.zeros(W)
+            if kind == "impulse":
+                frame[5] = 20000.0
+            s, fb = vec(frame), L.MFCCCreateVector(P)
+            te, te2 = C.c_double(), C.c_double()
+            L.Wave2FBank(s, fb, C.byref(te), C.byref(te2), info)
+            assert L.MFCCCompatStatus() == 0
+            wf, wte, wte2, wspec = oracle.wave2fbank(frame, sr, P, lo, hi)
+            assert np.max(np.abs(arr(fb) - wf)) < 1e-10
+            assert abs(te.value - wte) <= 1e-12 * max(wte, 1.0)
+            assert abs(te2.value - wte2) <= 1e-12 * max(wte2, 1.0)
+            spec = np.array([info.x[i + 1] for i in range(info.fftN)])
+            assert np.max(np.abs(spec - wspec)) <= 1e-11 * max(1.0, float(np.max(np.abs(wspec))))
+            c = L.MFCCCreateVector(13)
+            L.FBank2MFCC(fb, c, 13)
+            wm, wc0 = oracle.fbank2mfcc(wf, 13)
+            assert np.max(np.abs(arr(c) - wm)) < 1e-9
+            assert abs(L.FBank2C0(fb) - wc0) < 1e-9
+            for v in (s, fb, c):
+                L.MFCCFreeVector(v)
+        L.MFCCFreeFBank(C.byref(info))
+    for n in (4, 64, 512, 4096):
+        x = rng.standard_normal(n)
+        for inv in (0, 1):
+            v = vec(x)
+            L.FFT(v, inv)
+            assert np.max(np.abs(arr(v) - oracle.fft(x, inv))) < 1e-10 * np.sqrt(n)
+            L.MFCCFreeVector(v)
+        v = vec(x)
+        L.Realft(v)
+        assert np.max(np.abs(arr(v) - oracle.realft(x))) < 1e-10 * np.sqrt(n)
+        L.MFCCFreeVector(v)

@@ -46,6 +46,22 @@ delwin = 9 ;
 """
 
 
+def test_compat_library_exports_the_reference_names():
+    """libmfcc_compat.so loads and exports every function include/mfcc_compat.h declares (the
+    reference's names of mfcc.h:29-74 plus the vector helpers); no compute call without a GPU."""
+    header = open(os.path.join(ROOT, "include", "mfcc_compat.h")).read()
+    body = header[header.index("} FBankInfo;"):]
+    declared = set(re.findall(r"\b([A-Za-z][A-Za-z0-9]+)\s*\((?:int|Vector|const|FBankInfo|void)", body))
+    assert declared == set(ma.COMPAT_EXPORTS), declared ^ set(ma.COMPAT_EXPORTS)
+    L = ma.compat_lib()
+    for name in ma.COMPAT_EXPORTS:
+        assert hasattr(L, name), name
+    v = L.MFCCCreateVector(5)
+    assert L.MFCCVectorSize(v) == 5 and v[1] == 0.0
+    L.MFCCFreeVector(v)
+    assert abs(L.Mel(3, 0.01) - 1127 * np.log(1 + 2 * 0.01)) < 1e-12
+
+
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "mfcc_amd.h")).read()
     declared = set(re.findall(r"\b(MFCC[A-Za-z0-9]+)\s*\(", header))
