@@ -82,7 +82,7 @@ struct MFCCPlan {
     // whole-utterance finishing pass (deltas + z-norm from compact static rows), see finish.hip
     bool uttFinish = false;
     void *dStatics = nullptr; // totalRows x vSize
-    int finSubRows = 0, finStaticElems = 0, finRedOffset = 0;
+    int finSubRows = 0, finStaticElems = 0, finRedOffset = 0, finRegRows = 0;
     size_t finLds = 0;
     int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
     std::vector<float> melW;
@@ -654,6 +654,14 @@ static int finish_plan(MFCCPlan *p)
                 p->finLds = total;
             }
         }
+        if (p->uttFinish) { // register variant: sub-tiles of rowLanes rows, at most kFinishRegRows per lane
+            const int rowLanes = kFinishBlock / std::min(kFinishBlock, c->vSize);
+            p->finRegRows = (maxFrames <= (int64_t)kFinishRegRows * rowLanes && !getenv("MFCC_NO_FINISH_REG")) ? 1 : 0;
+            // (its two first-delta buffers of rowLanes + 2 delwin rows must fit where the sub-tile buffers are)
+            if (p->finRegRows && 2 * (rowLanes + 2 * c->cfg.delwin) * c->vSize >
+                                     (p->finSubRows + 2 * c->cfg.delwin) * c->vSize + p->finSubRows * c->step)
+                p->finRegRows = 0;
+        }
         if (p->uttFinish)
             HIP_TRY(hipMalloc(&p->dStatics, std::max<size_t>((size_t)p->totalRows * c->vSize * elb, 16)));
     }
@@ -1018,6 +1026,7 @@ static int run_finish(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
     a.staticElems = p->finStaticElems;
     a.redOffset = p->finRedOffset;
     a.znorm = c->cfg.znormFlag ? 1 : 0;
+    a.regRows = p->finRegRows;
     a.sigmaT2 = 2.0 * sigmaT2;
     const int rc = launch_utt_finish(c->cfg.precision, &a, c->cfg.regreOrder, p->numUtts, p->finLds, stream);
     if (rc) return set_error("finishing kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;

@@ -134,6 +134,136 @@ __global__ __launch_bounds__(kFinishBlock) void k_utt_finish(const FinishArgs<T>
     }
 }
 
+// The same for utterances of at most KMAX * rowLanes rows: a lane keeps the deltas of its KMAX rows
+// in registers across the statistics barrier, so every delta is formed once, and writes its
+// finished values straight to the output row (the three pieces of a row leave the wave back to
+// back and merge in L2).  Sub-tiles are rowLanes rows: one row per lane per round.
+template <typename T, int ORD, int KMAX>
+__global__ __launch_bounds__(kFinishBlock) void k_utt_finish_reg(const FinishArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    const int W = a.vSize, dw = a.delwin, step = a.step;
+    const UttDesc ud = a.utts[blockIdx.x];
+    const int n = ud.numFrames, tid = threadIdx.x;
+    if (n <= 0) return;
+    constexpr int H1 = ORD == 3 ? 1 : 0;
+    constexpr int NX = ORD > 1 ? ORD - 1 : 1;
+    T *S = reinterpret_cast<T *>(fsm);
+    T *D1base = S + a.staticElems; // two buffers of (rowLanes + 2 delwin) x W, used in turn: one barrier per round
+    double *red = reinterpret_cast<double *>(fsm + a.redOffset);
+    double *ms = red + 2 * kFinishBlock;
+
+    const T *src = a.statics + ud.outRow * W;
+    for (int i = tid; i < n * W; i += kFinishBlock) S[i] = src[i];
+    __syncthreads();
+
+    const int ncol = min(kFinishBlock, W), rowLanes = kFinishBlock / ncol;
+    const int col = tid % ncol, rl = tid / ncol;
+    const bool live = rl < rowLanes;
+    const int hrows = H1 * dw;
+    const float sigmaF = (float)a.sigmaT2;
+    auto quotient = [&](T sum) -> T {
+        if constexpr (sizeof(T) == 4)
+            return sum / sigmaF;
+        else
+            return (T)((double)sum / a.sigmaT2);
+    };
+
+    T xr[KMAX][NX];
+    double s1[ORD], s2[ORD];
+#pragma unroll
+    for (int o = 0; o < ORD; ++o) s1[o] = s2[o] = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int s = k * rowLanes;
+        if (s < n) { // block-uniform
+            const int rows = min(rowLanes, n - s);
+            T *D1 = D1base + (k & 1) * (rowLanes + 2 * dw) * W;
+            if constexpr (ORD >= 2) {
+                if (live)
+                    for (int p = rl; p < rows + 2 * hrows; p += rowLanes) {
+                        const int t = min(max(s - hrows + p, 0), n - 1);
+                        T sum = 0;
+                        for (int tau = 1; tau <= dw; ++tau)
+                            sum += (T)tau * (S[min(t + tau, n - 1) * W + col] - S[max(t - tau, 0) * W + col]);
+                        D1[p * W + col] = quotient(sum);
+                    }
+                __syncthreads();
+            }
+            if (live && rl < rows) {
+                double xd = (double)S[(s + rl) * W + col];
+                s1[0] += xd;
+                s2[0] += xd * xd;
+                if constexpr (ORD >= 2) {
+                    xr[k][0] = D1[(rl + hrows) * W + col];
+                    xd = (double)xr[k][0];
+                    s1[1] += xd;
+                    s2[1] += xd * xd;
+                }
+                if constexpr (ORD >= 3) {
+                    T sum = 0;
+                    for (int tau = 1; tau <= dw; ++tau)
+                        sum += (T)tau * (D1[(rl + hrows + tau) * W + col] - D1[(rl + hrows - tau) * W + col]);
+                    xr[k][1] = quotient(sum);
+                    xd = (double)xr[k][1];
+                    s1[2] += xd;
+                    s2[2] += xd * xd;
+                }
+            }
+        }
+    }
+    double mean[ORD], rstd[ORD];
+#pragma unroll
+    for (int o = 0; o < ORD; ++o) mean[o] = 0.0, rstd[o] = 1.0;
+    if (a.znorm) {
+#pragma unroll
+        for (int o = 0; o < ORD; ++o) {
+            red[tid] = s1[o];
+            red[kFinishBlock + tid] = s2[o];
+            __syncthreads();
+            if (tid < ncol) {
+                double t1 = 0, t2 = 0;
+                for (int q = 0; q < rowLanes; ++q) {
+                    t1 += red[q * ncol + tid];
+                    t2 += red[kFinishBlock + q * ncol + tid];
+                }
+                const double cnt = (double)n;
+                const double m = t1 / cnt;
+                double var = t2 / cnt - m * m;
+                if (var < 0) var = 0;
+                ms[o * W + tid] = m;
+                ms[step + o * W + tid] = 1.0 / sqrt(var);
+            }
+            __syncthreads();
+        }
+        if (live) {
+#pragma unroll
+            for (int o = 0; o < ORD; ++o) {
+                mean[o] = ms[o * W + col];
+                rstd[o] = ms[step + o * W + col];
+            }
+        }
+    }
+    T *dst = a.out + ud.outRow * step;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int row = k * rowLanes + rl;
+        if (live && row < n) {
+            T *o = dst + (long long)row * step + col;
+            T x[ORD];
+            x[0] = S[row * W + col];
+#pragma unroll
+            for (int q = 1; q < ORD; ++q) x[q] = xr[k][q - 1];
+#pragma unroll
+            for (int q = 0; q < ORD; ++q) {
+                T v = x[q];
+                if (a.znorm) v = (T)(((double)v - mean[q]) * rstd[q]);
+                o[q * W] = v;
+            }
+        }
+    }
+}
+
 template <typename T, int ORD>
 int launch_one(const FinishArgs<T> &a, int numUtts, size_t lds, hipStream_t st)
 {
@@ -141,6 +271,15 @@ int launch_one(const FinishArgs<T> &a, int numUtts, size_t lds, hipStream_t st)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_utt_finish<T, ORD>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+    }
+    if (a.regRows > 0) { // every utterance has at most kFinishRegRows rows per lane
+        if (lds > 48 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_utt_finish_reg<T, ORD, kFinishRegRows>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL((k_utt_finish_reg<T, ORD, kFinishRegRows>), dim3(numUtts), dim3(kFinishBlock), lds, st, a);
+        return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((k_utt_finish<T, ORD>), dim3(numUtts), dim3(kFinishBlock), lds, st, a);
     return (int)hipGetLastError();

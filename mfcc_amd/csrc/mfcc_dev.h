@@ -111,6 +111,7 @@ struct DeltaArgs {
 
 // Whole-utterance finishing pass (finish.hip)
 constexpr int kFinishBlock = 512; // threads per workgroup (one workgroup per utterance)
+constexpr int kFinishRegRows = 32; // rows per lane the register variant holds
 template <typename T>
 struct FinishArgs {
     const T *statics;   // totalRows x vSize, compact
@@ -121,6 +122,7 @@ struct FinishArgs {
     int staticElems;    // elements reserved in LDS for the longest utterance's static rows
     int redOffset;      // byte offset of the reduction scratch (2 kFinishBlock + 2 step doubles) in LDS
     int znorm;
+    int regRows;        // > 0: no utterance has more than kFinishRegRows rows per lane (register variant)
     double sigmaT2;
 };
 
