@@ -15,10 +15,15 @@ from mfcc_amd.presets import CONFIGS  # noqa: E402
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    opts = dict(zip(sys.argv[1:], sys.argv[2:]))
-    utts = int(opts.get("--utts", 10000))
-    seconds = float(opts.get("--seconds", 10))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("preset")
+    ap.add_argument("overrides", nargs="*")
+    ap.add_argument("--utts", type=int, default=10000)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ns = ap.parse_args()
+    args = [ns.preset] + ns.overrides
+    utts, seconds = ns.utts, ns.seconds
     kw = dict(CONFIGS[args[0]])
     for a in args[1:]:
         k, v = a.split("=")
