@@ -30,17 +30,20 @@ def column_kinds(kw):
     return kinds
 
 
-def assert_static_close(got, ref, kw, f64=False, delta=False):
+def assert_static_close(got, ref, kw, f64=False, delta=False, static_ref=None):
     """Tolerances for the static block: log-mel / log-energy 1e-4 absolute; cepstra and C0 1e-5
     relative to the largest cepstral magnitude of the matrix; ZCR exact (the same crossing count,
     the quotient rounded to single precision); brightness / sub-band
     fractions 1e-5 absolute; debug FFT magnitudes 1e-5 relative to the largest magnitude.
     In f64 mode everything must agree to 1e-9 (relative to magnitude).  delta=True: the block holds
-    regression deltas; they inherit the tolerances, except that a ZCR delta is 1e-6 absolute."""
+    regression deltas; they inherit the tolerances, except that a ZCR delta is 1e-6 absolute, and
+    the relative ones (cepstra, magnitudes) stay relative to the static block `static_ref` the
+    deltas were formed from (a delta is a difference of those values divided by a constant >= 2)."""
     kinds = column_kinds(kw) * kw.get("vecNum", 1)
     assert got.shape == ref.shape
     n = len(kinds)
     g, r = got[:, :n], ref[:, :n]
+    sr = r if static_ref is None else np.where(np.isfinite(static_ref[:, :n]), static_ref[:, :n], 0.0)
     assert np.array_equal(np.isnan(g), np.isnan(r))
     assert np.array_equal(np.isinf(g), np.isinf(r))
     fin = np.isfinite(r)
@@ -64,14 +67,14 @@ def assert_static_close(got, ref, kw, f64=False, delta=False):
         if not m.any() or g.shape[0] == 0:
             continue
         if kind in ("cep", "c0"):
-            mx = float(np.max(np.abs(r[:, (kinds == "cep") | (kinds == "c0")])))
+            mx = float(np.max(np.abs(sr[:, (kinds == "cep") | (kinds == "c0")])))
         else:
-            mx = float(np.max(np.abs(r[:, m])))
+            mx = float(np.max(np.abs(sr[:, m])))
         if kind == "zc" and not delta:  # exact: the same count / (wlen - 1), rounded once to single precision
             assert np.array_equal(g[:, m], r[:, m].astype(np.float32).astype(np.float64))
             continue
         err = float(np.max(np.abs(g[:, m] - r[:, m])))
-        assert err <= atol_of(mx), "%s: max error %g > %g" % (kind, err, atol_of(mx))
+        assert err <= atol_of(mx), "%s%s: max error %g > %g" % (kind, " (delta block)" if delta else "", err, atol_of(mx))
 
 
 def run_product_batch(ma, cfg, pcm_list, channels, bps, device=0, pad=None):
