@@ -1436,11 +1436,35 @@ __global__ __launch_bounds__(kBlock) void k_colstats(const StatArgs<T> a)
     }
 }
 
-// One workgroup per utterance: chunk partials summed in chunk order -> mean and 1/std.
+// Sum of the partial rows [first, first + count) of a 2*step-column table, for columns
+// [c0, c0 + ncol): the workgroup's lanes form kBlock / ncol row groups, group g adds rows
+// g, g + groups, ... in order, and the group sums are added in group order, so the result does not
+// depend on timing.  sh holds kBlock doubles.  Returns the total in the lanes tid < ncol.
+__device__ __forceinline__ double partial_column_sum(const double *partial, long long first, int count, int width,
+                                                      int c0, int ncol, double *sh)
+{
+    const int tid = threadIdx.x, groups = kBlock / ncol;
+    const int col = tid % ncol, g = tid / ncol;
+    double s = 0;
+    if (g < groups)
+        for (int q = g; q < count; q += groups) s += partial[(first + q) * width + c0 + col];
+    __syncthreads();
+    sh[tid] = s;
+    __syncthreads();
+    double t = 0;
+    if (tid < ncol)
+        for (int q = 0; q < groups; ++q) t += sh[q * ncol + tid];
+    return t;
+}
+
+constexpr int kFinalCols = 16; // columns per workgroup of the finalise kernels
+
+// One workgroup per utterance and group of kFinalCols columns: chunk partials -> mean and 1/std.
 // byBlock: the partials are per regression block (k_delta) instead of per statistics chunk.
 __global__ __launch_bounds__(kBlock) void k_colfinal(const UttDesc *utts, const double *partial,
                                                      double *stats, int step, int byBlock)
 {
+    __shared__ double sh[kBlock];
     const int u = blockIdx.x;
     UttDesc ud = utts[u];
     int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
@@ -1448,18 +1472,20 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(const UttDesc *utts, const 
         nchunk = (ud.numFrames + kRegRows - 1) / kRegRows;
         ud.statBegin = ud.regBegin;
     }
-    for (int c = threadIdx.x; c < step; c += kBlock) {
-        double s = 0, s2 = 0;
-        for (int q = 0; q < nchunk; ++q) {
-            s += partial[(long long)(ud.statBegin + q) * 2 * step + c];
-            s2 += partial[(long long)(ud.statBegin + q) * 2 * step + step + c];
+    // blockIdx.y owns kFinalCols columns: kBlock / kFinalCols row groups
+    {
+        const int c0 = blockIdx.y * kFinalCols;
+        const int ncol = min(kFinalCols, step - c0);
+        const double s = partial_column_sum(partial, ud.statBegin, nchunk, 2 * step, c0, ncol, sh);
+        const double s2 = partial_column_sum(partial, ud.statBegin, nchunk, 2 * step, step + c0, ncol, sh);
+        if ((int)threadIdx.x < ncol) {
+            const double n = (double)ud.ownCount;
+            const double mean = s / n;
+            double var = s2 / n - mean * mean;
+            if (var < 0) var = 0;
+            stats[(long long)u * 2 * step + c0 + threadIdx.x] = mean;
+            stats[(long long)u * 2 * step + step + c0 + threadIdx.x] = 1.0 / sqrt(var);
         }
-        const double n = (double)ud.ownCount;
-        const double mean = s / n;
-        double var = s2 / n - mean * mean;
-        if (var < 0) var = 0;
-        stats[(long long)u * 2 * step + c] = mean;
-        stats[(long long)u * 2 * step + step + c] = 1.0 / sqrt(var);
     }
 }
 
@@ -1467,18 +1493,20 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(const UttDesc *utts, const 
 __global__ __launch_bounds__(kBlock) void k_shardfinal(const UttDesc *utts, const double *partial,
                                                        double *sums, int step, int byBlock)
 {
+    __shared__ double sh[kBlock];
     UttDesc ud = utts[0];
     int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
     if (byBlock) {
         nchunk = (ud.numFrames + kRegRows - 1) / kRegRows;
         ud.statBegin = ud.regBegin;
     }
-    for (int c = threadIdx.x; c < 2 * step; c += kBlock) {
-        double s = 0;
-        for (int q = 0; q < nchunk; ++q) s += partial[(long long)(ud.statBegin + q) * 2 * step + c];
-        sums[c] = s;
+    {
+        const int c0 = blockIdx.y * kFinalCols;
+        const int ncol = min(kFinalCols, 2 * step - c0);
+        const double s = partial_column_sum(partial, ud.statBegin, nchunk, 2 * step, c0, ncol, sh);
+        if ((int)threadIdx.x < ncol) sums[c0 + threadIdx.x] = s;
     }
-    if (threadIdx.x == 0) sums[2 * step] = (double)ud.ownCount;
+    if (threadIdx.x == 0 && blockIdx.y == 0) sums[2 * step] = (double)ud.ownCount;
 }
 
 // SHARD: sums holds all-reduced {sum x, sum x^2 per column, count}; otherwise stats holds the
@@ -1761,7 +1789,7 @@ int launch_colstats(int precision, const void *args, int numChunks, void *stream
 int launch_colfinal(const StatArgs<float> &a, int numUtts, bool byBlock, void *stream)
 {
     if (numUtts <= 0) return 0;
-    hipLaunchKernelGGL(k_colfinal, dim3(numUtts), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(k_colfinal, dim3(numUtts, (a.step + kFinalCols - 1) / kFinalCols), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        a.utts, a.partial, a.stats, a.step, byBlock ? 1 : 0);
     return (int)hipGetLastError();
 }
@@ -1769,7 +1797,7 @@ int launch_colfinal(const StatArgs<float> &a, int numUtts, bool byBlock, void *s
 int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, double *sumsOut, void *stream)
 {
     (void)numChunks;
-    hipLaunchKernelGGL(k_shardfinal, dim3(1), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(k_shardfinal, dim3(1, (2 * a.step + kFinalCols - 1) / kFinalCols), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        a.utts, a.partial, sumsOut, a.step, byBlock ? 1 : 0);
     return (int)hipGetLastError();
 }
