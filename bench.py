@@ -25,12 +25,13 @@ HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E
 
 WORKLOADS = {
     # name: (key in mfcc_amd.presets.CONFIGS, channels, bytes/sample, seconds, utterances,
-    #        algorithmic bytes per frame, description)
-    "c2": ("c2", 1, 2, 10.0, 10000, 480,
+    #        algorithmic bytes per frame of the whole pass, of the static-feature kernel alone
+    #        (PCM read + its own rows written), description)
+    "c2": ("c2", 1, 2, 10.0, 10000, 480, 480,
            "16 kHz mono 25ms/10ms, 40-bin log-mel FBank (fbankFlag=1), 10000 x 10 s utterances per GPU"),
-    "c3": ("c3", 1, 2, 10.0, 10000, 860,
+    "c3": ("c3", 1, 2, 10.0, 10000, 860, 380,
            "16 kHz 13 MFCC+C0+energy, regreOrder=3 (delwin=2) + znorm, 10000 x 10 s utterances per GPU"),
-    "c4": ("c4", 2, 3, 60.0, 256, 5692,
+    "c4": ("c4", 2, 3, 60.0, 256, 5692, 5692,
            "44.1 kHz 24-bit stereo vecNum=2, 40 MFCC + ZCR/brightness/8 sub-bands, 256 x 60 s files per GPU"),
 }
 
@@ -122,7 +123,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    key, channels, bps, seconds, n_utts, bytes_per_frame, desc = WORKLOADS[args.workload]
+    key, channels, bps, seconds, n_utts, pass_bytes_per_frame, bytes_per_frame, desc = WORKLOADS[args.workload]
     if args.utts:
         n_utts = args.utts
     kw = CONFIGS[key]
@@ -196,7 +197,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "kernel": "k_front (static features)", "kernel_ms": kavg * 1e3,
-                         "algorithmic_bytes_per_frame": bytes_per_frame},
+                         "algorithmic_bytes_per_frame": bytes_per_frame,
+                         "whole_pass": {"algorithmic_bytes_per_frame": pass_bytes_per_frame,
+                                        "frac": frames * pass_bytes_per_frame * args.steps / elapsed / HBM_PEAK}},
         }
         if not args.no_host and world == 1:
             # Same pass with the batch starting and ending in pinned host memory (what a caller
