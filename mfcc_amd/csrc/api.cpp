@@ -96,7 +96,7 @@ struct MFCCPlan {
     TileDesc *dTiles = nullptr;
     void *dStageTw = nullptr;
     std::vector<double> stageTw;
-    int maxSeg = 1, zPitch = 0;
+    int maxSeg = 1, zPitch = 0, melPieces = 1;
     std::vector<int32_t> laneSeg;
     double *dPartial = nullptr, *dStats = nullptr;
     unsigned long long *dSums2 = nullptr;
@@ -266,7 +266,13 @@ static int choose_tile(MFCCPlan *p)
     const int lanes = front_lanes(log2nc, pplog);
     // work area of one frame: nc complex points with one pad point per 16, or the nc (t1, ek-t1)
     // pairs, the 2 (P+1) segment sums and the 2 S sub-band sums behind them, whichever is larger
-    int zPitch = (std::max(2 * (nc + nc / 16), 2 * nc + std::max(2 * (c->cfg.bankNum + 1), 16) + 2 * c->cfg.subBandEFlag) + 3) & ~3;
+    // Mel segments longer than a few bins are cut into up to 4 parts when the frame has lanes to
+    // spare (one round must still hold every part): the parts are summed by different lanes.
+    int pieces = 1;
+    while (pieces < 4 && (pieces + 1) * (c->cfg.bankNum + 1) <= lanes) ++pieces;
+    if (getenv("MFCC_MEL_PIECES")) pieces = std::max(1, std::min(4, atoi(getenv("MFCC_MEL_PIECES")))); // tuning aid
+    p->melPieces = pieces;
+    int zPitch = (std::max(2 * (nc + nc / 16), 2 * nc + std::max(2 * pieces * (c->cfg.bankNum + 1), 16) + 2 * c->cfg.subBandEFlag) + 3) & ~3;
     p->zPitch = zPitch;
     {
         // Per-stage twiddle blocks, laid out as the kernel's fft_stages reads them: for a stage
@@ -291,13 +297,23 @@ static int choose_tile(MFCCPlan *p)
         // Mel segments: segment s (0..P) = the bins whose lower channel is s (contiguous, because
         // loChan never decreases over the pass band); a segment without bins still gets a slot, so
         // that its sums are written as zeros.
-        const int P1 = c->cfg.bankNum + 1;
-        std::vector<int> sb(P1, 0), se(P1, 0);
+        const int S1 = c->cfg.bankNum + 1;
+        std::vector<int> segB(S1, 0), segE(S1, 0);
         for (int k = 0; k < nc; ++k) {
             const int ch = c->tab.loChan[k];
-            if (ch < 0 || ch >= P1) continue;
-            if (se[ch] == 0) sb[ch] = k;
-            se[ch] = k + 1;
+            if (ch < 0 || ch >= S1) continue;
+            if (segE[ch] == 0) segB[ch] = k;
+            segE[ch] = k + 1;
+        }
+        // part j of segment s is entry j * S1 + s (the slot its sums are stored in)
+        const int P1 = S1 * pieces;
+        std::vector<int> sb(P1, 0), se(P1, 0);
+        for (int sIdx = 0; sIdx < S1; ++sIdx) {
+            const int len = segE[sIdx] - segB[sIdx];
+            for (int j = 0; j < pieces; ++j) {
+                sb[j * S1 + sIdx] = segB[sIdx] + (int)((long)len * j / pieces);
+                se[j * S1 + sIdx] = segB[sIdx] + (int)((long)len * (j + 1) / pieces);
+            }
         }
         // Every round each lane sums one segment, 4 bins per step; the lanes of a frame read
         // 8-byte entries from 32 LDS banks, so segments of one round whose first bins share a bank
@@ -914,6 +930,7 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.loWt = static_cast<const T *>(c->dLoWt);
     a.laneSeg = p->dLaneSeg;
     a.maxSeg = p->maxSeg;
+    a.melPieces = p->melPieces;
     a.pairAligned = (c->cfg.inc % 2 == 0) ? 1 : 0;
     a.zPitch = p->zPitch;
     a.dctT = static_cast<const T *>(c->dDct);

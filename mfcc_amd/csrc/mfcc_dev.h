@@ -66,6 +66,7 @@ struct FrontArgs {
     const T *loWt;         // nc
     const int32_t *laneSeg;   // lanes-per-frame x maxSeg x 4: {first bin, end bin, segment index or -1, 0}
     int maxSeg;               // mel segments (bins sharing one lower channel) a lane sums at most
+    int melPieces;            // parts a segment is cut into (different lanes), summed in part order
     int pairAligned;          // 1: every frame starts on an even sample of its row (inc is even)
     int zPitch;               // elements per frame work area
     const T *dctT;         // (M + c0) x dctPitch, j-major: cos(pi (j+1) (k + 0.5) / P), then a row of ones

@@ -860,7 +860,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             T *Zt = zbuf + grp * a.zPitch;
             cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
             cpx<T> *AB = Z;                               // per bin (loWt*p, p - loWt*p)
-            T *Tt = Zt + 2 * NC, *Ut = Tt + a.P + 1;      // per-segment sums of the two
+            T *Tt = Zt + 2 * NC, *Ut = Tt + a.melPieces * (a.P + 1); // per-segment (and part) sums of the two
             T *Pw = Zt;                                   // plain power values, before AB
             T *fbk = fbkSep + item * a.P;                 // log-mel values of the item (only if fbkElems)
             T *fo = feat + item * a.D;
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     int lpb = 1;
                     while (lpb * 2 * nseg <= G && lpb < 64) lpb *= 2;
                     const int perPass = G / lpb;
-                    T *bandE = Zt + 2 * NC + 2 * (a.P + 1); // behind the mel segment sums
+                    T *bandE = Zt + 2 * NC + 2 * a.melPieces * (a.P + 1); // behind the mel segment sums
                     for (int b0 = 0; b0 < nseg; b0 += perPass) {
                         const int b = b0 + l / lpb, sl = l & (lpb - 1);
                         T e = 0, ek = 0;
@@ -1163,7 +1163,8 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             STAMP(5);
             // ---- mel filterbank (mfcc.c:152-163).  The bins whose lower channel is c form one
             //      contiguous segment; its sums T[c] = sum t1 and U[c] = sum (ek - t1) are taken in
-            //      bin order, by the lane the host's balancing gave the segment to, and channel b is
+            //      bin order, by the lane the host's balancing gave the segment to (long segments are
+            //      cut into melPieces parts on different lanes when lanes are spare), and channel b is
             //      U[b-1] + T[b]; then log(max(., 1))  (mfcc.c:171-176).
             for (int sidx = 0; sidx < (SKIP(5) ? 0 : a.maxSeg); ++sidx) {
                 const int4 sg = lseg[l * a.maxSeg + sidx];
@@ -1188,7 +1189,12 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             }
             group_sync<G>();
             for (int ch = l; ch < (SKIP(6) ? 0 : a.P); ch += G) {
-                const T m = Ut[ch] + Tt[ch + 1];
+                T mu = Ut[ch], mt = Tt[ch + 1]; // parts of a segment in part (= bin) order
+                for (int j = 1; j < a.melPieces; ++j) {
+                    mu += Ut[j * (a.P + 1) + ch];
+                    mt += Tt[j * (a.P + 1) + ch + 1];
+                }
+                const T m = mu + mt;
                 const T lv = tlog<T>(m < (T)1 ? (T)1 : m);
                 if (active && a.fbkElems) fbk[ch] = lv;
                 if (active && a.fbankFlag) fo[ch] = lv;
