@@ -7,6 +7,9 @@ Two modes, matching how the reference's work divides:
     combined with one tiny exchange before the normalisation pass.
 Nothing here computes features; the arithmetic stays in libmfcc_amd.so.
 """
+import os
+import re
+
 import numpy as np
 
 
@@ -70,3 +73,59 @@ def recording_channel_sums(ma, ctx, pcm_dev, channels, bytes_per_sample, first_i
     instants [first_instant, first_instant + count) of its own buffer, then the ranks add up."""
     local = ma.channel_sums(ctx, pcm_dev, channels, bytes_per_sample, first_instant, count)
     return combine_sums(local, dist)
+
+
+def split_file_list(ini_path, rank, world_size, out_dir, file_list=None):
+    """This rank's share of a run: reads the `src<TAB>dst` list the ini names (main.c:173-177: up
+    to the first blank line), gives every rank the files shard_files assigns it by size on disk
+    (longest first; a missing file counts as empty and is reported by the rank that gets it), and
+    writes `rank<r>.list` and `rank<r>.ini` (the original ini with its fileList line replaced) into
+    out_dir.  file_list: the list path, if the caller already parsed the ini.
+    Returns (path of the per-rank ini, indices of this rank's lines)."""
+    text = open(ini_path, encoding="utf-8-sig").read()
+    key = re.compile(r"^(\s*fileList\s*[=:]\s*)([^;#\n]*?)(\s*(?:[;#].*)?)$", re.M)
+    m = key.search(text)
+    if file_list is None:
+        if not m:
+            raise ValueError("%s names no fileList" % ini_path)
+        file_list = m.group(2).strip()
+    lines = []
+    with open(file_list) as f:
+        for line in f:
+            if line == "\n":
+                break
+            lines.append(line if line.endswith("\n") else line + "\n")
+    sizes = []
+    for line in lines:
+        src = line.split("\t")[0]
+        try:
+            sizes.append(os.path.getsize(src))
+        except OSError:
+            sizes.append(0)
+    mine = shard_files(sizes, world_size)[rank]
+    os.makedirs(out_dir, exist_ok=True)
+    lst = os.path.join(out_dir, "rank%d.list" % rank)
+    with open(lst, "w") as f:
+        f.writelines(lines[i] for i in mine)
+    ini = os.path.join(out_dir, "rank%d.ini" % rank)
+    with open(ini, "w") as f:
+        f.write(key.sub(lambda mm: mm.group(1) + lst + mm.group(3), text, count=1) if m
+                else text + "\n[IO]\nfileList = %s\n" % lst)
+    return ini, mine
+
+
+def wapper_list_sharded(ma, ini_path, out_dir, dist=None):
+    """The whole run (MFCCWapperList = main.c:98-300) over the GPUs of a node: every rank takes its
+    share of the file list (split_file_list) and runs it on its own GPU; nothing is exchanged on
+    the data path.  Returns (failed files of this rank, failed files of all ranks)."""
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    ini, _ = split_file_list(ini_path, rank, world, out_dir)
+    failed = ma.wapper_list(ini)
+    total = failed
+    if world > 1:
+        import torch
+        t = torch.tensor([failed], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        total = int(t.item())
+    return failed, total

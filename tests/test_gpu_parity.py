@@ -549,3 +549,36 @@ def test_reference_named_functions_on_one_based_vectors(oracle):
         L.Realft(v)
         assert np.max(np.abs(arr(v) - oracle.realft(x))) < 1e-10 * np.sqrt(n)
         L.MFCCFreeVector(v)
+
+
+def test_file_sharded_whole_run(tmp_path):
+    """The whole-run entry point over ranks (files sharded by rank, nothing exchanged): the two
+    ranks of a world of 2, run one after the other on this GPU, together write every output, each
+    equal to the per-file entry point's."""
+    from mfcc_amd import sharding
+    kw = dict(CONFIGS["c2"])
+    cfg = ma.make_config(saveType=ma.SAVE_B, **kw)
+    lines, pcms = [], []
+    for i in range(9):
+        pcm = _pcm(2000 + 900 * i, 1, 2, 300 + i, 16000)
+        pcms.append(pcm)
+        (tmp_path / ("u%d.wav" % i)).write_bytes(ma.wav_bytes(pcm, 1, 2, 16000))
+        lines.append("%s\t%s" % (tmp_path / ("u%d.wav" % i), tmp_path / ("u%d.bin" % i)))
+    lst = tmp_path / "all.list"
+    lst.write_text("\n".join(lines) + "\n")
+    ini = tmp_path / "config.ini"
+    ini.write_text("[Frame]\nsampleRate = 16000\nhipassfre = %s\nlowpassfre = %s\npreemphasise = %s\nwlen = %d\n"
+                   "inc = %d\nvecNum = 1\n[MFCC]\nfbankFlag = 1\nbankNum = %d\n[Others]\nenergyFlag = %d\n"
+                   "[Regression]\nregreOrder = 1\n[IO]\nsaveType = b\nnumThreads = 2\nfileList = %s\n" % (
+                       kw["hipassfre"], kw["lowpassfre"], kw["preemphasise"], kw["wlen"], kw["inc"], kw["bankNum"],
+                       kw.get("energyFlag", 0), lst))
+    os.environ["MFCC_QUIET"] = "1"
+    for rank in range(2):
+        rini, mine = sharding.split_file_list(str(ini), rank, 2, str(tmp_path / "ranks"))
+        assert len(mine) in (4, 5)
+        assert ma.wapper_list(rini) == 0
+    step = ma.step(cfg)
+    for i, pcm in enumerate(pcms):
+        got = np.fromfile(tmp_path / ("u%d.bin" % i), dtype=np.float64).reshape(-1, step)
+        assert np.array_equal(got, ma.wapper_mem(cfg, ma.wav_bytes(pcm, 1, 2, 16000)))
+    assert sharding.wapper_list_sharded(ma, str(ini), str(tmp_path / "one")) == (0, 0)

@@ -172,3 +172,31 @@ def test_frame_sharded_flow_world2_gloo(oracle, name, n, ch, bps):
     both = np.concatenate([got[0][0], got[1][0]])
     assert both.shape == ref.shape
     assert np.allclose(both, ref, rtol=1e-9, atol=1e-9)
+
+
+def test_split_file_list_covers_every_line_once(tmp_path):
+    """The per-rank lists of a sharded run: every line up to the first blank one lands on exactly
+    one rank, balanced by file size, and the per-rank ini differs from the original only in its
+    fileList line (comment suffix kept)."""
+    lines = []
+    for i in range(11):
+        src = tmp_path / ("s%02d.wav" % i)
+        if i != 4:  # one missing file: counted as empty, still assigned
+            src.write_bytes(b"x" * (100 + 37 * i * i))
+        lines.append("%s\t%s" % (src, tmp_path / ("d%02d.txt" % i)))
+    lst = tmp_path / "all.list"
+    lst.write_text("\n".join(lines) + "\n\nignored\tafter the blank line\n")
+    ini = tmp_path / "config.ini"
+    ini.write_text("[Frame];\nsampleRate = 16000 ;\nfileList = %s ; the list\nwlen = 400 ;\n" % lst)
+    seen, loads = [], []
+    for rank in range(3):
+        rini, mine = sharding.split_file_list(str(ini), rank, 3, str(tmp_path / "ranks"))
+        seen += mine
+        got = open(tmp_path / "ranks" / ("rank%d.list" % rank)).read().splitlines()
+        assert got == [lines[i] for i in mine]
+        text = open(rini).read()
+        assert "fileList = %s ; the list" % (tmp_path / "ranks" / ("rank%d.list" % rank)) in text
+        assert text.replace(str(tmp_path / "ranks" / ("rank%d.list" % rank)), str(lst)) == ini.read_text()
+        loads.append(sum(os.path.getsize(lines[i].split("\t")[0]) for i in mine if i != 4))
+    assert sorted(seen) == list(range(11))
+    assert max(loads) - min(loads) <= 100 + 37 * 100  # within one largest file
