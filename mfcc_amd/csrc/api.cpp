@@ -717,7 +717,7 @@ extern "C" int MFCCPlanCreate(MFCCContext *c, int channels, int bytesPerSample, 
     if (!c || !out || nUtts < 0 || (nUtts > 0 && (!byteOff || !numSamples)))
         return set_error("bad argument to MFCCPlanCreate"), MFCC_E_ARG;
     *out = nullptr;
-    if (channels < 1 || channels > 2 || bytesPerSample < 2 || bytesPerSample > 4)
+    if (channels < 1 || channels > 2 || bytesPerSample < 1 || bytesPerSample > 4)
         return set_error("unsupported PCM layout: %d channels x %d bytes", channels, bytesPerSample), MFCC_E_WAV;
     const int rows = channels == 2 ? 4 : channels; /* main.c:198-199 */
     if (c->cfg.vecNum > rows)
@@ -785,7 +785,7 @@ extern "C" int MFCCPlanCreateShard(MFCCContext *c, int channels, int bytesPerSam
 {
     if (!c || !out || totalSamples < 0) return set_error("bad argument to MFCCPlanCreateShard"), MFCC_E_ARG;
     *out = nullptr;
-    if (channels < 1 || channels > 2 || bytesPerSample < 2 || bytesPerSample > 4)
+    if (channels < 1 || channels > 2 || bytesPerSample < 1 || bytesPerSample > 4)
         return set_error("unsupported PCM layout"), MFCC_E_WAV;
     const int rows = channels == 2 ? 4 : channels;
     if (c->cfg.vecNum > rows) return set_error("vecnum %d > num_channels %d", c->cfg.vecNum, channels), MFCC_E_VECNUM;
@@ -1180,7 +1180,7 @@ extern "C" int MFCCChannelSums(MFCCContext *c, const void *pcmDev, int channels,
                                int64_t sampleBegin, int64_t count, int64_t *sums2Dev, void *stream)
 {
     if (!c || !sums2Dev || (count > 0 && !pcmDev)) return set_error("bad argument"), MFCC_E_ARG;
-    if (channels < 1 || channels > 2 || bytesPerSample < 2 || bytesPerSample > 4)
+    if (channels < 1 || channels > 2 || bytesPerSample < 1 || bytesPerSample > 4)
         return set_error("unsupported PCM layout"), MFCC_E_WAV;
     DEVICE_SCOPE(c->device);
     HIP_TRY(hipMemsetAsync(sums2Dev, 0, 4 * sizeof(int64_t), static_cast<hipStream_t>(stream)));

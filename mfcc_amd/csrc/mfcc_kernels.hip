@@ -141,6 +141,7 @@ __device__ __forceinline__ int lds_sample(const unsigned *raw, int p, int bps)
 {
     const int w = p >> 2;
     const unsigned v = __builtin_amdgcn_alignbyte(raw[w + 1], raw[w], (unsigned)(p & 3));
+    if (bps == 1) return (int)(v & 0xffu) - 128; // 8-bit WAV PCM is unsigned, offset 128
     if (bps == 2) return (int)(short)(v & 0xffffu);
     if (bps == 3) return ((int)(v << 8)) >> 8;
     return (int)v;
@@ -1560,6 +1561,7 @@ __global__ __launch_bounds__(kBlock) void k_normalize(const StatArgs<T> a, const
 
 __device__ __forceinline__ int gmem_sample(const unsigned char *p, int bps)
 {
+    if (bps == 1) return (int)p[0] - 128;
     if (bps == 2) return (int)(short)((unsigned)p[0] | ((unsigned)p[1] << 8));
     if (bps == 3) {
         const unsigned v = (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16);

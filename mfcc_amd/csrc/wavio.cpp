@@ -48,8 +48,8 @@ int wav_parse(const unsigned char *f, size_t len, WavInfo &w)
             blockAlign = (int)le16(body + 12);
             const int bits = (int)le16(body + 14);
             w.bytesPerSample = bits / 8;
-            if (bits % 8 != 0 || w.bytesPerSample < 2 || w.bytesPerSample > 4)
-                return set_error("%d-bit PCM is not supported (16, 24 or 32)", bits), MFCC_E_WAV;
+            if (bits % 8 != 0 || w.bytesPerSample < 1 || w.bytesPerSample > 4)
+                return set_error("%d-bit PCM is not supported (8, 16, 24 or 32)", bits), MFCC_E_WAV;
             if (w.channels < 1 || w.channels > 2)
                 return set_error("%d channels are not supported (1 or 2)", w.channels), MFCC_E_WAV;
             if (blockAlign != w.channels * w.bytesPerSample)

@@ -420,6 +420,7 @@ int orc_extract(const orc_config *c, const int32_t *pcm, int numChannels, long n
 
 static int32_t pcm_sample(const uint8_t *p, int bytesPerSample)
 {
+    if (bytesPerSample == 1) return (int32_t)p[0] - 128; /* 8-bit WAV PCM is unsigned, offset 128 */
     if (bytesPerSample == 2) return (int16_t)(p[0] | (p[1] << 8));
     if (bytesPerSample == 3) {
         int32_t v = p[0] | (p[1] << 8) | (p[2] << 16);

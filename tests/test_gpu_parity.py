@@ -24,6 +24,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _pcm(n, ch, bps, seed, sr, tone=440):
+    if bps == 1:  # 8-bit WAV PCM is unsigned: the top byte of a 16-bit sample, offset 128
+        p16 = ma.synth_pcm(n, ch, 2, seed=0x5EED0000 + seed, sample_rate=sr, tone_hz=tone).reshape(-1, 2)
+        return (p16[:, 1] ^ 0x80).astype(np.uint8).copy()
     if bps == 4:  # the generator makes 16- and 24-bit samples: widen 24-bit ones, low byte varied
         p24 = ma.synth_pcm(n, ch, 3, seed=0x5EED0000 + seed, sample_rate=sr, tone_hz=tone).reshape(-1, 3)
         out = np.empty((p24.shape[0], 4), dtype=np.uint8)
@@ -192,7 +195,7 @@ def test_ragged_batch_and_edge_lengths(oracle, finish, monkeypatch):
             assert np.all(np.isnan(g))
 
 
-@pytest.mark.parametrize("ch,bps", [(1, 2), (2, 2), (1, 3), (2, 3), (1, 4), (2, 4)])
+@pytest.mark.parametrize("ch,bps", [(1, 1), (2, 1), (1, 2), (2, 2), (1, 3), (2, 3), (1, 4), (2, 4)])
 @pytest.mark.parametrize("shift", [0, 1, 2, 3, 6])
 def test_pcm_layouts_and_misaligned_offsets(oracle, ch, bps, shift):
     """Every sample size / channel count, with the utterance starting at odd byte offsets."""

@@ -174,9 +174,12 @@ def test_wav_info_variants():
     assert e.value.code == ma.E_WAV
     trunc = ma.wav_bytes(pcm, 2, 3, 44100)[:-600]  # data size field larger than the file
     assert ma.wav_info(trunc)["numSamples"] == 233
-    eight_bit = bytearray(ma.wav_bytes(b"\0" * 100, 1, 1, 8000))
+    info = ma.wav_info(ma.wav_bytes(b"\x80" * 100, 1, 1, 8000))  # 8-bit PCM (unsigned) is accepted
+    assert (info["bytesPerSample"], info["numSamples"]) == (1, 100)
+    twelve_bit = bytearray(ma.wav_bytes(b"\0" * 100, 1, 2, 8000))
+    twelve_bit[34:36] = (12).to_bytes(2, "little")
     with pytest.raises(ma.MFCCError):
-        ma.wav_info(bytes(eight_bit))
+        ma.wav_info(bytes(twelve_bit))
 
 
 def test_wav_info_matches_oracle(oracle):
