@@ -236,12 +236,13 @@ int MFCCRealftDevice(int precision, void *dataDev, int numFrames, int n, void *s
 int MFCCWave2FBankDevice(MFCCContext *ctx, const void *framesDev, int numFrames, void *fbankDev,
                          void *teDev, void *stream);
 /* The same with explicit tables and every output of the reference's function: InitFBank's results
- * for any (frameSize, sampPeriod, numChans, lopass, hipass) come from MFCCFBankTables (host, double;
- * alpha = 1, doubleFFT = 0 as at main.c:168; entry [k-1] = the reference's [k]; loChan/loWt are
- * uploaded by the caller), usePower / takeLogs as in FBankInfo (mfcc.c:154-157,171-176); te2Dev
+ * for any argument set come from MFCCFBankTables (host, double; doubleFFT mfcc.c:55-56 and the
+ * alpha / warpLowCut / warpUpCut warping of mfcc.c:17-36,83-92 included; entry [k-1] = the reference's
+ * [k]; loChan/loWt are uploaded by the caller), usePower / takeLogs as in FBankInfo (mfcc.c:154-157,171-176); te2Dev
  * (mfcc.c:164-168) and specDev (numFrames x fftN: the packed spectrum the reference leaves in info.x,
  * read by main.c:235-236) may be NULL. */
 int MFCCFBankTables(int frameSize, double sampPeriod, int numChans, double lopass, double hipass,
+                    int doubleFFT, double alpha, double warpLowCut, double warpUpCut,
                     int *fftN, int *klo, int *khi, double *fres, double *cf, int *loChan, double *loWt,
                     char *passband, size_t cap);
 int MFCCWave2FBankTablesDevice(int precision, const void *framesDev, int numFrames, int frameSize,

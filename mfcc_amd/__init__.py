@@ -144,7 +144,8 @@ def lib():
     L.MFCCFBank2MFCCDevice.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.MFCCMel.argtypes = [C.c_int, C.c_double]
     L.MFCCMel.restype = C.c_double
-    L.MFCCFBankTables.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int),
+    L.MFCCFBankTables.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
+                                  C.c_double, C.c_double, C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int), dp, dp, C.POINTER(C.c_int), dp,
                                   C.c_char_p, C.c_size_t]
     L.MFCCWave2FBankTablesDevice.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,

@@ -1242,13 +1242,15 @@ extern "C" int MFCCFBank2MFCCDevice(MFCCContext *c, const void *fbankDev, int nu
 }
 
 extern "C" int MFCCFBankTables(int frameSize, double sampPeriod, int numChans, double lopass, double hipass,
+                               int doubleFFT, double alpha, double warpLowCut, double warpUpCut,
                                int *fftN, int *klo, int *khi, double *fres, double *cf, int *loChan, double *loWt,
                                char *passband, size_t cap)
 {
-    if (frameSize < 1 || numChans < 1 || !(sampPeriod > 0.0))
+    if (frameSize < 1 || numChans < 1 || !(sampPeriod > 0.0) || !(alpha > 0.0))
         return set_error("bad argument to MFCCFBankTables"), MFCC_E_ARG;
     Tables t;
-    build_fbank(frameSize, sampPeriod, numChans, lopass, hipass, t);
+    build_fbank(frameSize, sampPeriod, numChans, lopass, hipass, t, doubleFFT, alpha, warpLowCut, warpUpCut);
+    if (t.fftN > (2 << kMaxLog2Nc)) return set_error("fftN %d is outside the supported range", t.fftN), MFCC_E_CONFIG;
     if (fftN) *fftN = t.fftN;
     if (klo) *klo = t.klo;
     if (khi) *khi = t.khi;

@@ -82,19 +82,13 @@ extern "C" FBankInfo InitFBank(int frameSize, double sampPeriod, int numChans, d
                                int usePower, int takeLogs, int doubleFFT, double alpha, double warpLowCut,
                                double warpUpCut)
 {
-    (void)warpLowCut, (void)warpUpCut;
     FBankInfo fb;
     memset(&fb, 0, sizeof fb);
     g_status = 0;
-    if (doubleFFT || alpha != 1.0) { // dead at the reference's only call site (main.c:168)
-        g_status = MFCC_E_CONFIG;
-        fprintf(stderr, "InitFBank: doubleFFT and alpha != 1 are not supported\n");
-        return fb;
-    }
     int fftN = 0;
     char text[256] = "";
-    if (MFCCFBankTables(frameSize, sampPeriod, numChans, lopass, hipass, &fftN, nullptr, nullptr, nullptr, nullptr,
-                        nullptr, nullptr, nullptr, 0)) {
+    if (MFCCFBankTables(frameSize, sampPeriod, numChans, lopass, hipass, doubleFFT, alpha, warpLowCut, warpUpCut,
+                        &fftN, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0)) {
         fail(MFCC_E_ARG, "InitFBank");
         return fb;
     }
@@ -110,8 +104,8 @@ extern "C" FBankInfo InitFBank(int frameSize, double sampPeriod, int numChans, d
         MFCCFreeFBank(&fb);
         return fb;
     }
-    MFCCFBankTables(frameSize, sampPeriod, numChans, lopass, hipass, &fb.fftN, &fb.klo, &fb.khi, &fb.fres, fb.cf + 1,
-                    fb.loChan + 1, fb.loWt + 1, text, sizeof text);
+    MFCCFBankTables(frameSize, sampPeriod, numChans, lopass, hipass, doubleFFT, alpha, warpLowCut, warpUpCut, &fb.fftN,
+                    &fb.klo, &fb.khi, &fb.fres, fb.cf + 1, fb.loChan + 1, fb.loWt + 1, text, sizeof text);
     fputs(text, stdout); /* mfcc.c:74-75 */
     BankEntry e;
     e.key = fb.loWt;

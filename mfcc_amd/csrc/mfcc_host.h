@@ -26,7 +26,8 @@ struct Tables {
 };
 
 int build_tables(const MFCCConfig &cfg, Tables &t);
-int build_fbank(int frameSize, double sampPeriod, int numChans, double lopass, double hipass, Tables &t);
+int build_fbank(int frameSize, double sampPeriod, int numChans, double lopass, double hipass, Tables &t,
+                int doubleFFT, double alpha, double warpLowCut, double warpUpCut);
 int validate_config(const MFCCConfig &cfg);
 inline int eff_mfccnum(const MFCCConfig &c) { return c.fbankFlag ? c.bankNum : c.MFCCNum; }
 inline int eff_c0(const MFCCConfig &c) { return c.fbankFlag ? 0 : (c.MFCC0thFlag ? 1 : 0); }

@@ -10,12 +10,27 @@ namespace mfcc {
 
 static double mel_of_bin(int k, double fres) { return 1127 * log(1 + (k - 1) * fres); } // mfcc.c:13
 
-// InitFBank (mfcc.c:39-122) for alpha == 1.0, doubleFFT == 0.
-int build_fbank(int frameSize, double sampPeriod, int numChans, double lopass, double hipass, Tables &t)
+// WarpFreq (mfcc.c:17-36): piecewise-linear vocal-tract-length warping of a centre frequency.
+static double warp_freq(double fcl, double fcu, double freq, double minFreq, double maxFreq, double alpha)
+{
+    if (alpha == 1.0) return freq;
+    const double scale = 1.0 / alpha;
+    const double cu = fcu * 2 / (1 + scale), cl = fcl * 2 / (1 + scale);
+    const double au = (maxFreq - cu * scale) / (maxFreq - cu), al = (cl * scale - minFreq) / (cl - minFreq);
+    if (freq > cu) return au * (freq - cu) + scale * cu;
+    if (freq < cl) return al * (freq - minFreq) + minFreq;
+    return scale * freq;
+}
+
+// InitFBank (mfcc.c:39-122).  The extraction path calls it as main.c:168 does (doubleFFT = 0,
+// alpha = 1.0); the other values serve callers of the lower-level API.
+int build_fbank(int frameSize, double sampPeriod, int numChans, double lopass, double hipass, Tables &t,
+                int doubleFFT, double alpha, double warpLowCut, double warpUpCut)
 {
     const int P = numChans, maxChan = P + 1;
     t.fftN = 2;
     while (frameSize > t.fftN) t.fftN *= 2; // mfcc.c:53-54
+    if (doubleFFT) t.fftN *= 2;             // mfcc.c:55-56
     t.nc = t.fftN / 2;
     t.log2nc = 0;
     while ((1 << t.log2nc) < t.nc) ++t.log2nc;
@@ -41,8 +56,15 @@ int build_fbank(int frameSize, double sampPeriod, int numChans, double lopass, d
     // centre frequencies, mfcc.c:77-82
     t.cf.assign(maxChan, 0.0);
     const double ms = t.mhi - t.mlo;
-    for (int chan = 1; chan <= maxChan; ++chan)
-        t.cf[chan - 1] = ((double)chan / (double)maxChan) * ms + t.mlo;
+    for (int chan = 1; chan <= maxChan; ++chan) {
+        double cf = ((double)chan / (double)maxChan) * ms + t.mlo;
+        if (alpha != 1.0) { // mfcc.c:83-92: scale assuming scaling starts at lopass
+            const double minFreq = 700.0 * (exp(t.mlo / 1127.0) - 1.0), maxFreq = 700.0 * (exp(t.mhi / 1127.0) - 1.0);
+            cf = 700 * (exp(cf / 1127.0) - 1.0);
+            cf = 1127.0 * log(1.0 + warp_freq(warpLowCut, warpUpCut, cf, minFreq, maxFreq, alpha) / 700.0);
+        }
+        t.cf[chan - 1] = cf;
+    }
 
     // lower channel of each bin, mfcc.c:96-104
     t.loChan.assign(half, -1);
@@ -69,7 +91,7 @@ int build_tables(const MFCCConfig &cfg, Tables &t)
 {
     const double sampPeriod = 1e7 / (double)cfg.sampleRate; // main.c:141
     const int P = cfg.bankNum;
-    build_fbank(cfg.wlen, sampPeriod, P, cfg.lowpassfre, cfg.hipassfre, t);
+    build_fbank(cfg.wlen, sampPeriod, P, cfg.lowpassfre, cfg.hipassfre, t, 0, 1.0, 0.0, 0.0); // main.c:168
     // Hamming window: HTK GenHamWindow, w[i] = 0.54 - 0.46 cos(2 pi (i-1) / (W-1))
     t.window.resize(cfg.wlen);
     {

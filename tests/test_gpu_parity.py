@@ -585,3 +585,66 @@ def test_file_sharded_whole_run(tmp_path):
         got = np.fromfile(tmp_path / ("u%d.bin" % i), dtype=np.float64).reshape(-1, step)
         assert np.array_equal(got, ma.wapper_mem(cfg, ma.wav_bytes(pcm, 1, 2, 16000)))
     assert sharding.wapper_list_sharded(ma, str(ini), str(tmp_path / "one")) == (0, 0)
+
+
+def test_init_fbank_with_warping_and_double_fft(oracle):
+    """InitFBank's options that main.c:168 leaves off (doubleFFT, alpha with warpLowCut/warpUpCut,
+    mfcc.c:17-36,55-56,83-92) and FBankInfo's usePower = 0 / takeLogs = 0 (mfcc.c:154-157,171-176),
+    through the reference-named functions: tables against a restatement of those lines here,
+    Wave2FBank against a direct evaluation with numpy's FFT."""
+    import ctypes as C
+    L = ma.compat_lib()
+    W, sr, P, lo, hi, alpha, wl, wu = 400, 16000, 24, 60.0, 7600.0, 1.1, 300.0, 5000.0
+    sp = 1e7 / sr
+    info = L.InitFBank(W, sp, P, lo, hi, 0, 0, 1, alpha, wl, wu)
+    assert L.MFCCCompatStatus() == 0 and info.fftN == 1024
+    N, nby2 = info.fftN, info.fftN // 2
+    fres = 1.0e7 / (sp * N * 700.0)
+    mel = lambda k: 1127 * np.log(1 + (k - 1) * fres)
+    mlo, mhi = 1127 * np.log(1 + lo / 700.0), 1127 * np.log(1 + hi / 700.0)
+    klo, khi = max(2, int(lo * sp * 1.0e-7 * N + 2.5)), min(nby2, int(hi * sp * 1.0e-7 * N + 0.5))
+    assert (info.klo, info.khi) == (klo, khi)
+
+    def warp(fcl, fcu, f, fmin, fmax, a):
+        scale = 1.0 / a
+        cu, cl = fcu * 2 / (1 + scale), fcl * 2 / (1 + scale)
+        au, al = (fmax - cu * scale) / (fmax - cu), (cl * scale - fmin) / (cl - fmin)
+        return au * (f - cu) + scale * cu if f > cu else (al * (f - fmin) + fmin if f < cl else scale * f)
+
+    fmin, fmax = 700.0 * (np.exp(mlo / 1127.0) - 1.0), 700.0 * (np.exp(mhi / 1127.0) - 1.0)
+    cf = []
+    for chan in range(1, P + 2):
+        c = chan / (P + 1) * (mhi - mlo) + mlo
+        c = 700 * (np.exp(c / 1127.0) - 1.0)
+        cf.append(1127.0 * np.log(1.0 + warp(wl, wu, c, fmin, fmax, alpha) / 700.0))
+    got_cf = np.array([info.cf[i + 1] for i in range(P + 1)])
+    assert np.max(np.abs(got_cf - np.array(cf))) < 1e-9
+    lo_chan = np.array([info.loChan[i + 1] for i in range(nby2)])
+    lo_wt = np.array([info.loWt[i + 1] for i in range(nby2)])
+    assert np.all(lo_chan[:klo - 1] == -1) and np.all(lo_chan[khi:] == -1)
+    assert np.all(np.diff(lo_chan[klo - 1:khi]) >= 0) and lo_chan[khi - 1] <= P
+    # magnitude mode without logs, against numpy
+    rng = np.random.default_rng(3)
+    frame = rng.standard_normal(W) * 2000.0
+    s = L.MFCCCreateVector(W)
+    for i, x in enumerate(frame):
+        s[i + 1] = float(x)
+    fb = L.MFCCCreateVector(P)
+    te, te2 = C.c_double(), C.c_double()
+    L.Wave2FBank(s, fb, C.byref(te), C.byref(te2), info)
+    assert L.MFCCCompatStatus() == 0
+    spec = np.fft.rfft(frame, N)
+    want = np.zeros(P + 2)
+    for k in range(klo, khi + 1):
+        ek = abs(spec[k - 1]) if k > 1 else abs(spec[0].real + spec[nby2].real)
+        b, t1 = lo_chan[k - 1], lo_wt[k - 1] * ek
+        if b > 0:
+            want[b] += t1
+        if b < P:
+            want[b + 1] += ek - t1
+    got = np.array([fb[i + 1] for i in range(P)])
+    assert np.max(np.abs(got - want[1:P + 1])) < 1e-8 * max(1.0, float(np.max(want)))
+    assert abs(te.value - float(np.sum(frame * frame))) < 1e-6 * te.value
+    L.MFCCFreeVector(s)
+    L.MFCCFreeVector(fb)
+    L.MFCCFreeFBank(C.byref(info))
