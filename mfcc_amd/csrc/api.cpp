@@ -678,6 +678,10 @@ static int finish_plan(MFCCPlan *p)
                                      (p->finSubRows + 2 * c->cfg.delwin) * c->vSize + p->finSubRows * c->step)
                 p->finRegRows = 0;
         }
+        if (getenv("MFCC_DEBUG"))
+            fprintf(stderr, "mfcc plan: deltas / z-norm by %s (longest utterance %lld frames, %zu B of LDS)\n",
+                    !p->uttFinish ? "row blocks" : (p->finRegRows ? "whole-utterance kernel, registers" : "whole-utterance kernel, two sweeps"),
+                    (long long)maxFrames, p->finLds);
         if (p->uttFinish)
             HIP_TRY(hipMalloc(&p->dStatics, std::max<size_t>((size_t)p->totalRows * c->vSize * elb, 16)));
     }

@@ -648,3 +648,24 @@ def test_init_fbank_with_warping_and_double_fft(oracle):
     L.MFCCFreeVector(s)
     L.MFCCFreeVector(fb)
     L.MFCCFreeFBank(C.byref(info))
+
+
+@pytest.mark.parametrize("name,frames,force_sweeps", [("c3", 1000, False), ("c3", 1100, False), ("c3", 97, True),
+                                                      ("c1a", 100, False), ("c1a", 60, True), ("c3", 1400, False)])
+def test_whole_utterance_finish_variants(oracle, name, frames, force_sweeps, monkeypatch):
+    """Both forms of the whole-utterance delta / z-norm kernel: deltas kept in registers (at most
+    32 rows per lane: c3 1000 frames, c1a 100), the two-sweep form that longer utterances take (c3
+    1100 frames) or MFCC_NO_FINISH_REG forces, and the row-block kernels once the utterance no longer
+    fits the LDS budget (c3 1400 frames); ragged batch with a one-frame and an empty utterance."""
+    if force_sweeps:
+        monkeypatch.setenv("MFCC_NO_FINISH_REG", "1")
+    kw = dict(CONFIGS[name], znormFlag=1)
+    ch, bps = _layout(kw)
+    lens = [kw["wlen"] + (frames - 1) * kw["inc"] + 3, kw["wlen"], kw["wlen"] - 1, kw["wlen"] + 7 * kw["inc"]]
+    pcms = [_pcm(n, ch, bps, 500 + i, kw["sampleRate"]) for i, n in enumerate(lens)]
+    got = run_product_batch(ma, ma.make_config(**kw), [p.tobytes() for p in pcms], ch, bps)
+    ocfg = oracle.make_config(**kw)
+    assert got[0].shape[0] == frames and got[2].shape[0] == 0
+    for p, g in zip(pcms, got):
+        if g.shape[0] >= 5:
+            _compare(g, oracle.extract_pcm_bytes(ocfg, p, ch, bps), kw, False)
