@@ -151,7 +151,11 @@ extern "C" int MFCCContextCreate(const MFCCConfig *cfgIn, int device, MFCCContex
     c->step = c->vSize * cfg.regreOrder;
     const int p = cfg.precision;
     {
+        // Half the Hamming values: the half-size transform of the half-scaled frame makes the
+        // real-FFT split (mfcc.c:274-287) come out unscaled without a halving of its own; the
+        // kernel multiplies the frame energy by 4.  Scaling by a power of two is exact.
         std::vector<double> padded(c->tab.window);
+        for (double &w : padded) w *= 0.5;
         padded.resize((size_t)c->tab.fftN + 8, 0.0);
         if ((rc = upload_tab(p, padded, &c->dWindow))) return rc;
     }

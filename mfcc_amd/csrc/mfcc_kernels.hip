@@ -188,7 +188,7 @@ __device__ __forceinline__ double tsqrt<double>(double x) { return sqrt(x); }
 // compiler, neighbouring 8-byte reads are fused into ds_read2_b64, which moves 128 B/clk where two
 // ds_read_b64 move 256 B/clk.  N points at a constant byte stride are issued back to back and
 // drained by one wait, which also ties the results to that wait for the compiler's scheduler.
-typedef float v2f __attribute__((ext_vector_type(2)));
+typedef cpx<float> v2f;
 
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
@@ -239,7 +239,7 @@ __device__ __forceinline__ void lds_read_strided(cpx<float> *out, const void *ba
     if constexpr (N % 4 == 2) lds_drain(t[N - 2], t[N - 1]);
     if constexpr (N % 4 == 1) lds_drain(t[N - 1]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) out[i] = {t[i].x, t[i].y};
+    for (int i = 0; i < N; ++i) out[i] = t[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -349,6 +349,36 @@ __device__ __forceinline__ void fft_stages(LanePoints<T, LOG2NC, PPLOG> &v, cpx<
     if constexpr (LOGNS + RB < LOG2NC)
         fft_stages<T, LOG2NC, PPLOG, LOGNS + RB, TWOFF + (LOGNS > 0 ? (R - 1) * NS : 0), TWLDS, TWREG,
                    TWR + (LOGNS > 0 ? NB * (R - 1) : 0), KEEPLAST>(v, Z, l, tw, twr);
+}
+
+// Real-FFT split of one bin pair (mfcc.c:274-287) and the two powers (ek of mfcc.c:153-155).
+// za = Z[k], zb = Z[nc - k] of the half-size transform of HALF-scaled input (the window table holds
+// half the Hamming values), sw = (cos, sin)(pi k / nc).  With A = za + conj(zb), B = za - conj(zb):
+// X[k] = A + w' B and conj(X[nc - k]) = A - w' B = 2 A - X[k], w' = -i conj(sw) = (-sin, -cos).
+template <typename T>
+__device__ __forceinline__ void split_power(cpx<T> za, cpx<T> zb, cpx<T> sw, T &pa, T &pb)
+{
+    const cpx<T> A = {za.x + zb.x, za.y - zb.y}, B = {za.x - zb.x, za.y + zb.y};
+    const cpx<T> P = {A.x - sw.y * B.x + sw.x * B.y, A.y - sw.y * B.y - sw.x * B.x};
+    const cpx<T> Q = {(T)2 * A.x - P.x, (T)2 * A.y - P.y};
+    pa = P.x * P.x + P.y * P.y;
+    pb = Q.x * Q.x + Q.y * Q.y;
+}
+template <>
+__device__ __forceinline__ void split_power<float>(cpx<float> za, cpx<float> zb, cpx<float> sw, float &pa, float &pb)
+{
+    cpx<float> A, B, t, P;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(A) : "v"(za), "v"(zb));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(B) : "v"(za), "v"(zb));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
+        : "=v"(t)
+        : "v"(B), "v"(sw), "v"(A));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"
+        : "=v"(P)
+        : "v"(B), "v"(sw), "v"(t));
+    const cpx<float> Q = A * cpx<float>{2.0f, 2.0f} - P;
+    pa = P.x * P.x + P.y * P.y;
+    pb = Q.x * Q.x + Q.y * Q.y;
 }
 
 // Value of x in lane (16 - l) mod 16 of the same row of 16 lanes: mirror the row, then rotate it
@@ -772,7 +802,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                         sm[i] = (float)(short)((i & 1) ? (d[i >> 1] >> 16) : (d[i >> 1] & 0xffffu));
                     float y[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) y[i] = 8 * vj + i < ns ? sm[i + 1] - kf * sm[i] : 0.0f;
+                    for (int i = 0; i < 8; ++i) y[i] = sm[i + 1] - kf * sm[i]; // (finite behind the tile's last sample too: zeroed below)
                     float *dstRow = reinterpret_cast<float *>(rows) + 8 * vj;
                     *reinterpret_cast<float4 *>(dstRow) = make_float4(y[0], y[1], y[2], y[3]);
                     *reinterpret_cast<float4 *>(dstRow + 4) = make_float4(y[4], y[5], y[6], y[7]);
@@ -921,7 +951,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 cpx<T> e2 = {0, 0};
 #pragma unroll
                 for (int i = 0; i < PPL; ++i) e2 = {e2.x + v[i].x * v[i].x, e2.y + v[i].y * v[i].y};
-                te = e2.x + e2.y;
+                te = (T)4 * (e2.x + e2.y); // the window table holds half the Hamming values
             }
             STAMP(2);
             if (a.energyFlag) te = group_part<T, G>(te, red, tt);
@@ -986,19 +1016,15 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 const int k = l + G * q; // k == 0 (lane 0, q == 0) reads a don't-care word: fixed up below
                 const cpx<T> za = zas[q], zb = zbs[q];
                 const cpx<T> sw = LEAN ? swreg[q] : reinterpret_cast<const cpx<T> *>(split)[k];
-                const T c = sw.x, s = sw.y;
-                const T ex = (T)0.5 * (za.x + zb.x), ey = (T)0.5 * (za.y - zb.y);
-                const T ox = (T)0.5 * (za.y + zb.y), oy = (T)-0.5 * (za.x - zb.x);
-                const T wx = c * ox + s * oy, wy = c * oy - s * ox;
-                pa[q] = (ex + wx) * (ex + wx) + (ey + wy) * (ey + wy);
-                pb[q] = (ex - wx) * (ex - wx) + (ey - wy) * (ey - wy);
+                split_power<T>(za, zb, sw, pa[q], pb[q]);
             }
             {
                 // bin 0 packs Re + Im of Z[0] (mfcc.c:288-290); bin nc/2 is |Z[nc/2]|^2
                 // (register split: lane 0, the only user, holds Z[0] and Z[nc/2] = Z[16 * 8] itself)
                 const cpx<T> z0 = REGSPLIT ? v[0] : Z[0], zh = REGSPLIT ? v[PPL / 2] : Z[zpad(NC / 2)];
-                const T p0 = (z0.x + z0.y) * (z0.x + z0.y);
-                const T ph = NC > 1 ? zh.x * zh.x + zh.y * zh.y : (T)0;
+                // (the transform is that of half-scaled input)
+                const T p0 = (T)4 * (z0.x + z0.y) * (z0.x + z0.y);
+                const T ph = NC > 1 ? (T)4 * (zh.x * zh.x + zh.y * zh.y) : (T)0;
                 pa[0] = l == 0 ? p0 : pa[0];
                 pb[0] = l == 0 ? ph : pb[0];
             }
@@ -1713,11 +1739,15 @@ static int front_dispatch(int op, int log2nc, int pplog, bool tl, int mode, cons
     switch (log2nc * 8 + pplog) {
 #define MFCC_CASE(L, PL) \
     case L * 8 + PL: return front_do<T, L, PL>(op, tl, mode, args, numBlocks, lds, st);
+#ifdef MFCC_DEV_CASES // ISA listings of the benchmark instantiations only (tools/isa_blocks.py); never in the library
+        MFCC_CASE(8, 4) MFCC_CASE(10, 3) MFCC_CASE(10, 4)
+#else
         MFCC_CASE(1, 4) MFCC_CASE(2, 4) MFCC_CASE(3, 4) MFCC_CASE(4, 4) MFCC_CASE(5, 4)
         MFCC_CASE(6, 4) MFCC_CASE(7, 4) MFCC_CASE(8, 4) MFCC_CASE(9, 4) MFCC_CASE(10, 4)
         MFCC_CASE(11, 4) MFCC_CASE(12, 4) MFCC_CASE(13, 4)
         MFCC_CASE(6, 3) MFCC_CASE(7, 3) MFCC_CASE(8, 3) MFCC_CASE(9, 3) MFCC_CASE(10, 3) MFCC_CASE(11, 3)
         MFCC_CASE(6, 2) MFCC_CASE(7, 2) MFCC_CASE(8, 2) MFCC_CASE(9, 2) MFCC_CASE(10, 2)
+#endif
 #undef MFCC_CASE
     default: return -1;
     }
