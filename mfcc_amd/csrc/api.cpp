@@ -459,7 +459,7 @@ static int choose_tile(MFCCPlan *p)
                 for (int j = 0; j < 4; ++j) {
                     const int ln = 4 * (int)b + j, ch = 4 * pc.quad + j;
                     p->melMeta[4 * ln + 0] = r0[b];
-                    p->melMeta[4 * ln + 1] = (pc.pos >= 1 ? 1 : 0) | (owner ? 2 : 0) | (pc.pos >= 2 ? 4 : 0);
+                    p->melMeta[4 * ln + 1] = (pc.pos >= 1 ? 1 : 0) | (owner ? 2 : 0) | (pc.pos >= 2 ? 4 : 0) | (pc.pos >= 3 ? 8 : 0);
                     p->melMeta[4 * ln + 2] = (owner && ch < P) ? ch : -1;
                     if (ch >= P) continue;
                     for (int t = 0; t < steps; ++t) {

@@ -49,8 +49,8 @@ struct FrontArgs {
     int zeroMean;
     int lean;                 // kernel mode: 0 general, 1 lean, 2 lean with the matrix-core mel filterbank
     const float *melW;        // mode 2: melSteps x 64 weights, [step][lane]
-    const int32_t *melMeta;   // mode 2: 64 x {first bin of the lane's block, flags (1: add the block
-                              // before, 4: then the block two before, 2: writes results), channel or -1, 0}
+    const int32_t *melMeta;   // mode 2: 64 x {first bin of the lane's block, flags (1 / 4 / 8: add the block
+                              // one / two / three before, 2: writes results), channel or -1, 0}
     int melSteps;
     T *out;
     int numTiles;

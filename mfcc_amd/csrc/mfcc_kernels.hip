@@ -79,7 +79,7 @@ __device__ __forceinline__ V group_sum(V v, V *scratch, int tid)
     } else if constexpr (G <= 64 && sizeof(V) == 4) {
         // inside a row of 16 lanes through DPP (no LDS traffic), across rows by lane exchange
         auto dpp_add = [](V x, auto ctrl) {
-            const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false);
+            const int y = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true);
             return x + __builtin_bit_cast(V, y);
         };
         v = dpp_add(v, std::integral_constant<int, 0xB1>{});                        // quad_perm [1,0,3,2]
@@ -385,8 +385,9 @@ __device__ __forceinline__ void split_power<float>(cpx<float> za, cpx<float> zb,
 // right by one (data-parallel primitives, no LDS traffic).
 __device__ __forceinline__ float row_negated_lane(float x)
 {
-    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false); // row_mirror
-    const int r = __builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, false);                          // row_ror:1
+    // (every lane has a valid source lane, so no previous value has to be supplied)
+    const int m = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true); // row_mirror
+    const int r = __builtin_amdgcn_mov_dpp(m, 0x121, 0xf, 0xf, true);                          // row_ror:1
     return __builtin_bit_cast(float, r);
 }
 
@@ -647,7 +648,6 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
     T *featBase = zbuf + a.rawOrZElems;             // framesPerTile x vSize static features (+ VEC)
     T *fbkSep = featBase + a.featElems;             // framesPerTile x V x P log-mel values (cepstral mode)
     T *red = fbkSep + a.fbkElems;                   // 16 elements: 4 slots of per-wave sums
-    unsigned *warm = reinterpret_cast<unsigned *>(red + 16) + (tid & (TEAM - 1) & ~63); // prefetch sink, 4 B per lane
     unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
 
     const int bpi = F_channels * F_bps;
@@ -748,11 +748,18 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
 
     // Only the first activeTeams teams of a workgroup take tiles (fewer than NTEAMS when the
     // team regions of all of them would not fit the LDS); the others leave here.
+    // MELM: the sample pairs of the team's next round (same tile) are requested before the mel
+    // phase of the current one, so that their LDS latency is hidden behind it.
+    constexpr bool XPRE = false && MELM && sizeof(T) == 4 && PPL == R0;
+    cpx<T> xpre[XPRE ? PPL : 1];
+    bool xpreValid = false; // team-uniform
     const int tstride = gridDim.x * a.activeTeams;
     int tile = team < a.activeTeams ? blockIdx.x * a.activeTeams + team : a.numTiles;
     TileDesc td = {0, 0};
     if (tile < a.numTiles) td = a.tiles[tile];
+    unsigned warm0 = 0, warm1 = 0; // results of the cache-warming loads (see below)
     for (; tile < a.numTiles; tile += tstride) {
+        asm volatile("" ::"v"(warm0), "v"(warm1)); // the previous tile's warming loads end here
         const int nf = (int)((td.src >> 48) & 0xfffu);
         const int lead = (int)((td.src >> 60) & 1u);            // the first sample has a predecessor
         const unsigned char *g0 = a.pcm + (td.src & kTileOffMask);
@@ -866,18 +873,19 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
         team_sync<TEAM>();
         STAMP(1);
 
-        // Pull the next tile's cache lines towards L2 while this tile is computed: one 4-byte
-        // direct-to-LDS load per 128-byte line into a scratch word per lane (no register result,
-        // so nothing waits for it); the data itself is loaded when that tile starts.
+        // Pull the next tile's cache lines towards L2 while this tile is computed: one 4-byte load
+        // per 128-byte line (at most two per lane) whose results are only "used" when the next tile
+        // starts, so nothing waits for them; the data itself is loaded when that tile starts.
+        // (Loads into registers on purpose: a direct-to-LDS load would make every later LDS read of
+        // the tile wait for it.)
         if (tnext < a.numTiles && !SKIP(7)) {
             const int nfn = (int)((td.src >> 48) & 0xfffu);
             const int nbn = ((nfn - 1) * a.inc + a.wlen + 1) * bpi;
             const unsigned char *gn = a.pcm + (td.src & kTileOffMask);
-            for (int i = tt; i * 128 < nbn; i += TEAM)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) unsigned *)(
-                        reinterpret_cast<unsigned long long>(gn + i * 128) & ~3ull),
-                    (__attribute__((address_space(3))) unsigned *)warm, 4, 0, 0);
+            if (tt * 128 < nbn)
+                warm0 = *reinterpret_cast<const unsigned *>(reinterpret_cast<unsigned long long>(gn + tt * 128) & ~3ull);
+            if ((tt + TEAM) * 128 < nbn)
+                warm1 = *reinterpret_cast<const unsigned *>(reinterpret_cast<unsigned long long>(gn + (tt + TEAM) * 128) & ~3ull);
         }
 
         const int nItems = nf * F_V;
@@ -907,6 +915,14 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             if (SKIP(1)) {
 #pragma unroll
                 for (int i = 0; i < PPL; ++i) v[i] = {(T)(l + i), (T)(grp - i)};
+            } else if constexpr (XPRE) {
+                if (!xpreValid) {
+                    const volatile cpx<T> *xp = reinterpret_cast<const volatile cpx<T> *>(x + 2 * l);
+#pragma unroll
+                    for (int r = 0; r < R0; ++r) xpre[r] = xp[r * (NC / R0)];
+                }
+#pragma unroll
+                for (int r = 0; r < R0; ++r) v[r] = xpre[r] * cpx<T>{wreg[2 * r], wreg[2 * r + 1]};
             } else
 #pragma unroll
             for (int b = 0; b < PPL / R0; ++b) {
@@ -1144,20 +1160,41 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                 float av[kMelSteps];
 #pragma unroll
                 for (int t = 0; t < kMelSteps; ++t) av[t] = melA[t];
+                // two accumulators: the products of even and odd steps do not wait for each other
+                Acc4<float> macc2 = {0, 0, 0, 0};
 #pragma unroll
-                for (int t = 0; t < kMelSteps; ++t)
+                for (int t = 0; t < kMelSteps; t += 2) {
                     macc = __builtin_amdgcn_mfma_f32_4x4x1f32(slotLive ? av[t] : 0.0f, melW[t], macc, 0, 0, 0);
-                // a channel quad cut over up to 4 neighbouring blocks: add the block before, then
-                // the (already doubled) block two before; the chain's last block holds the sum
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float other = __shfl_up(macc[r], 4, 64);
-                    macc[r] += (melFlags & 1) ? other : 0.0f;
+                    macc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(slotLive ? av[t + 1] : 0.0f, melW[t + 1], macc2, 0, 0, 0);
                 }
+                macc += macc2;
+                if constexpr (XPRE) {
+                    xpreValid = base + GT < nItems && !SKIP(1);
+                    if (xpreValid) { // (slots past the tile's last frame read frame 0: finite, unused)
+                        const int itn = base + GT + grp < nItems ? base + GT + grp : 0;
+                        const volatile cpx<T> *xp = reinterpret_cast<const volatile cpx<T> *>(rows + itn * a.inc + 2 * l);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float other = __shfl_up(macc[r], 8, 64);
-                    macc[r] += (melFlags & 4) ? other : 0.0f;
+                        for (int r = 0; r < R0; ++r) xpre[r] = xp[r * (NC / R0)];
+                    }
+                }
+                // a channel quad cut over up to 4 neighbouring blocks: the chain's last block adds
+                // the sums of the (up to 3) blocks before it, fetched in one batch
+                {
+                    float o1[4], o2[4], o3[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        o1[r] = __shfl_up(macc[r], 4, 64);
+                        o2[r] = __shfl_up(macc[r], 8, 64);
+                        o3[r] = __shfl_up(macc[r], 12, 64);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float sum = macc[r];
+                        sum += (melFlags & 1) ? o1[r] : 0.0f;
+                        sum += (melFlags & 4) ? o2[r] : 0.0f;
+                        sum += (melFlags & 8) ? o3[r] : 0.0f;
+                        macc[r] = sum;
+                    }
                 }
                 if ((melFlags & 2) && melCh >= 0) { // owner of channel melCh: log(max(., 1)), mfcc.c:171-176
 #pragma unroll

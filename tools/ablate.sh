@@ -1,10 +1,11 @@
 #!/bin/bash
-# Phase ablation with the diagnostic library: time + LDS counters per skip mask (GPU box, repo root).
+# Phase ablation with the diagnostic library (results are wrong by design, only the time matters):
+# GPU box, repo root.  usage: tools/ablate.sh <workload> <mask> [<mask> ...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export MFCC_AMD_LIB=$PWD/mfcc_amd/libmfcc_amd_skip.so
-rm -rf gpurun_out/abl; mkdir -p gpurun_out/abl
+w=$1; shift
 for m in "$@"; do
   export MFCC_SKIP=$m
-  timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/abl/m$m -- python3 bench.py --steps 2 --warmup 1 --no-cpu > gpurun_out/abl/m$m.log 2>&1
-  echo "mask $m: $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/abl/m$m.log)"
+  timeout -k 10 120 python3 bench.py --workload $w --steps 5 --warmup 2 --no-cpu --no-host > /tmp/abl.json 2>/tmp/abl.err || { cat /tmp/abl.err | tail -5; exit 1; }
+  echo "mask $m: $(grep -o '"kernel_ms": [0-9.]*' /tmp/abl.json)"
 done
