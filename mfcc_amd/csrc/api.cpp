@@ -85,6 +85,7 @@ struct MFCCPlan {
     int finSubRows = 0, finStaticElems = 0, finRedOffset = 0, finRegRows = 0;
     size_t finLds = 0;
     int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
+    bool lean256 = false; // mode 2 run by the pipelined 256-point kernel
     std::vector<float> melW;
     std::vector<int32_t> melMeta;
     int melSteps = 0;
@@ -101,6 +102,7 @@ struct MFCCPlan {
     double *dPartial = nullptr, *dStats = nullptr;
     unsigned long long *dSums2 = nullptr;
     int64_t sampleBegin = 0, sampleCount = 0, ownedRowBegin = 0, ownedRows = 0;
+    int64_t planEnd = 0; // one past the last PCM byte the plan owns
     bool timing = false, timed = false;
     hipEvent_t evStart = nullptr, evStop = nullptr;
 };
@@ -553,6 +555,20 @@ static int choose_tile(MFCCPlan *p)
     p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
     // Lean instantiation: mono 16-bit input, one row, even frame shift, none of the per-frame extras.
     p->mode = (leanCand && (pplog == 3 || pplog == 4) && bestTab) ? (p->melSteps > 0 ? 2 : 1) : 0;
+    // The pipelined kernel for 256 complex points (lean256.hip) keeps only the cepstral table and the
+    // mel weights in the shared part of the LDS and has no staging area for finished rows.
+    p->lean256 = p->mode == 2 && useTeams == 4 && lean256_applies(log2nc, p->mode, bestFt, c->cfg.inc, c->cfg.wlen);
+    if (p->lean256) {
+        p->tabElems = (c->dctElems + kMelSteps * 64 + 3) & ~3;
+        p->featElems = 0;
+        p->teamElems = p->rowPitch + p->rawOrZElems + p->fbkElems + 16;
+        p->ldsBytes = ((size_t)p->tabElems + 4 * (size_t)p->teamElems) * sizeof(float);
+        p->blocksPerCu = (int)std::max<size_t>(1, std::min<size_t>(2, kLds / ((p->ldsBytes + 4095) & ~(size_t)4095)));
+        if (getenv("MFCC_DEBUG"))
+            fprintf(stderr, "mfcc plan: pipelined 256-point kernel, framesPerTile %d, LDS %zu B, workgroups/CU %d\n", bestFt,
+                    p->ldsBytes, p->blocksPerCu);
+        return MFCC_OK;
+    }
     const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->mode, p->ldsBytes);
     if (getenv("MFCC_DEBUG"))
         fprintf(stderr, "mfcc plan: points/lane %d, teams %d, mode %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
@@ -582,6 +598,7 @@ static int finish_plan(MFCCPlan *p)
             return set_error("batch too large: more than 2^31 tiles"), MFCC_E_ARG;
         d.regBegin = (int32_t)regBlocks;
         d.statBegin = (int32_t)chunks;
+        d.tileBegin = (int32_t)tiles;
         tiles += nt;
         chunks += ncb;
         regBlocks += nrb;
@@ -615,6 +632,7 @@ static int finish_plan(MFCCPlan *p)
         chunkUtt.insert(chunkUtt.end(), (size_t)((d.ownCount + kStatRows - 1) / kStatRows), u);
         regUtt.insert(regUtt.end(), (size_t)((d.numFrames + kRegRows - 1) / kRegRows), u);
     }
+    p->planEnd = planEnd;
     p->numRegBlocks = (int)regBlocks;
     p->numTiles = (int)tiles;
     p->numChunks = (int)chunks;
@@ -965,20 +983,33 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
         if (getenv("MFCC_STAMPS_DUMP")) {
             unsigned long long h[12];
             HIP_TRY(hipMemcpy(h, dStamps, sizeof h, hipMemcpyDeviceToHost));
-            unsigned long long tot = 0;
-            for (int i = 0; i < 12; ++i) tot += h[i];
-            fprintf(stderr, "mfcc stamps (cycle shares of all earlier launches):");
-            for (int i = 0; i < 12; ++i) fprintf(stderr, " [%d] %.1f%%", i, tot ? 100.0 * h[i] / tot : 0.0);
-            fprintf(stderr, "  total %llu\n", tot);
+            if (h[1])
+                fprintf(stderr, "mfcc stamps: interval [%s -> %s]: %.1f cycles x %.2f per tile = %.2f%% of the wave lifetimes\n",
+                        getenv("MFCC_STAMP_BEGIN") ? getenv("MFCC_STAMP_BEGIN") : "?",
+                        getenv("MFCC_STAMP_END") ? getenv("MFCC_STAMP_END") : "?", (double)h[0] / (double)h[1],
+                        (double)h[1] / std::max(1, p->numTiles), h[2] ? 100.0 * (double)h[0] / (double)h[2] : 0.0);
             HIP_TRY(hipMemset(dStamps, 0, 12 * sizeof(unsigned long long)));
         }
         a.stamps = dStamps;
         if (const char *e = getenv("MFCC_SKIP")) a.skip = atoi(e);
+        a.stampBegin = getenv("MFCC_STAMP_BEGIN") ? (int)strtol(getenv("MFCC_STAMP_BEGIN"), nullptr, 0) : 0;
+        a.stampEnd = getenv("MFCC_STAMP_END") ? atoi(getenv("MFCC_STAMP_END")) : -1;
     }
 #endif
     // persistent workgroups: as many as stay resident, each walks tiles with a grid stride
     const int teams = p->activeTeams;
     const int blocks = (int)std::min<int64_t>((p->numTiles + teams - 1) / teams, (int64_t)p->numCus * p->blocksPerCu);
+    if constexpr (sizeof(T) == 4) {
+        if (p->lean256) {
+            // every wave takes a contiguous run of tiles
+            a.numUtts = p->numUtts;
+            a.planEnd = p->planEnd;
+            a.tilesPerTeam = (p->numTiles + blocks * 4 - 1) / (blocks * 4);
+            const int rcl = launch_lean256(a, blocks, p->ldsBytes, stream);
+            if (rcl) return set_error("static-feature kernel launch failed (HIP error %d)", rcl), MFCC_E_DEVICE;
+            return MFCC_OK;
+        }
+    }
     const int rc = launch_front(c->cfg.precision, c->tab.log2nc, p->pplog, &a, blocks, p->ldsBytes, stream);
     if (rc) return set_error("static-feature kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;

@@ -23,7 +23,7 @@ struct UttDesc {
     int32_t ownBegin;   // first local frame that enters the z-norm statistics / is normalised
     int32_t ownCount;   // number of such frames
     int32_t statBegin;  // index of this utterance's first statistics chunk
-    int32_t pad;
+    int32_t tileBegin;  // tiles of all utterances before this one (its first tile's index)
     double mean[4];     // value subtracted from the derived rows {L, R, mid, side} (0 = option off)
 };
 
@@ -54,6 +54,9 @@ struct FrontArgs {
     int melSteps;
     T *out;
     int numTiles;
+    int numUtts;              // entries of utts (k_lean256 walks them)
+    int tilesPerTeam;         // k_lean256: consecutive tiles every wave takes
+    long long planEnd;        // k_lean256: one past the last PCM byte the plan owns
     int wlen, inc, framesPerTile;
     int V, channels, bps;
     int P, M, D, vSize, step;
@@ -81,8 +84,9 @@ struct FrontArgs {
     int winPad;            // elements reserved for the window inside that copy
     int featElems;         // elements of the static-feature staging area (framesPerTile x vSize, padded)
     int fbkElems;          // elements of the log-mel area, framesPerTile x V x P (0 in filterbank mode)
-    unsigned long long *stamps; // diagnostic builds only: 12 per-phase cycle sums (else NULL)
+    unsigned long long *stamps; // diagnostic builds only: {interval cycles, intervals, wave lifetimes} (else NULL)
     int skip;                   // diagnostic builds only: bit mask of phases to leave out
+    int stampBegin, stampEnd;   // diagnostic builds only: stamp sites that start / stop the clock
 };
 
 template <typename T>
@@ -140,6 +144,9 @@ struct StatArgs {
 
 int launch_front(int precision, int log2nc, int pplog, const void *args, int numBlocks,
                  size_t ldsBytes, void *stream);
+// lean256.hip: pipelined kernel for mono 16-bit, 256 complex points, matrix-core mel (mode 2 plans)
+bool lean256_applies(int log2nc, int mode, int framesPerTile, int inc, int wlen);
+int launch_lean256(const FrontArgs<float> &a, int numBlocks, size_t ldsBytes, void *stream);
 bool front_variant_exists(int log2nc, int pplog); // pplog: log2 of complex points per lane (4, 3, 2)
 int front_groups(int log2nc, int pplog);          // frames in flight per workgroup
 int front_teams(int log2nc, int pplog);           // independent teams (tile streams) per workgroup
