@@ -86,6 +86,7 @@ struct MFCCPlan {
     size_t finLds = 0;
     int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
     bool lean256 = false; // mode 2 run by the pipelined 256-point kernel
+    int leanWaves = 0;    // ... with this many waves per workgroup
     std::vector<float> melW;
     std::vector<int32_t> melMeta;
     int melSteps = 0;
@@ -402,22 +403,40 @@ static int choose_tile(MFCCPlan *p)
             if (k1 < k0) k0 = k1 = 0;
             q0[q] = k0, q1[q] = k1;
         }
+        // A chain must stay inside one row of 4 blocks (16 lanes), so that its partial sums can be
+        // added by row-wise lane shifts: chains are packed into the 4 rows longest first.
         int part = 0;
+        std::vector<int> chainStart(NQ, 0); // first block of quad q's chain
         for (int cand = 1; cand <= nc && !part && NQ <= 16; ++cand) {
-            int blocks = 0;
+            std::vector<int> order(NQ), len(NQ);
             bool ok = true;
             for (int q = 0; q < NQ; ++q) {
-                const int n = std::max(1, (q1[q] - q0[q] + cand - 1) / cand);
-                ok = ok && n <= 4;
-                blocks += n;
+                len[q] = std::max(1, (q1[q] - q0[q] + cand - 1) / cand);
+                ok = ok && len[q] <= 4;
+                order[q] = q;
             }
-            if (ok && blocks <= 16) part = cand;
+            if (!ok) continue;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len[x] > len[y]; });
+            int fill[4] = {0, 0, 0, 0};
+            for (int q : order) {
+                int row = -1;
+                for (int r = 0; r < 4 && row < 0; ++r)
+                    if (fill[r] + len[q] <= 4) row = r;
+                if (row < 0) {
+                    ok = false;
+                    break;
+                }
+                chainStart[q] = 4 * row + fill[row];
+                fill[row] += len[q];
+            }
+            if (ok) part = cand;
         }
-        std::vector<Piece> pieces;
+        // pieces[b]: what block b does (quad < 0: nothing)
+        std::vector<Piece> pieces(part ? 16 : 0, Piece{-1, 0, 0, 0, 1});
         for (int q = 0; q < NQ && part; ++q) {
             const int len = q1[q] - q0[q], n = std::max(1, (len + part - 1) / part);
             for (int i = 0; i < n; ++i) // equal parts, the first ones one bin longer
-                pieces.push_back({q, q0[q] + (int)((long)len * i / n), q0[q] + (int)((long)len * (i + 1) / n), i, n});
+                pieces[chainStart[q] + i] = {q, q0[q] + (int)((long)len * i / n), q0[q] + (int)((long)len * (i + 1) / n), i, n};
         }
         // Every block reads `steps` consecutive bins from r0 <= k0 (r0 + steps >= k1, inside the
         // frame).  The 32 lanes of a half wave (8 blocks x 4 frame slots, slots 8 banks apart)
@@ -431,13 +450,15 @@ static int choose_tile(MFCCPlan *p)
             std::vector<size_t> order(pieces.size());
             for (size_t i = 0; i < order.size(); ++i) order[i] = i;
             auto choices = [&](size_t b) {
+                if (pieces[b].quad < 0) return nc; // an idle block may start anywhere: placed last
                 return std::min(pieces[b].k0, nc - trial) - std::max(0, pieces[b].k1 - trial);
             };
             std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return choices(x) < choices(y); });
             char used[2][8] = {{0}};
             bool ok = true;
             for (size_t b : order) {
-                const int lo = std::max(0, pieces[b].k1 - trial), hi = std::min(pieces[b].k0, nc - trial);
+                const bool idle = pieces[b].quad < 0;
+                const int lo = idle ? 0 : std::max(0, pieces[b].k1 - trial), hi = idle ? std::min(7, nc - trial) : std::min(pieces[b].k0, nc - trial);
                 int pick = -1;
                 for (int r = hi; r >= lo && pick < 0; --r)
                     if (!used[b / 8][r & 7]) pick = r;
@@ -461,6 +482,7 @@ static int choose_tile(MFCCPlan *p)
                 for (int j = 0; j < 4; ++j) {
                     const int ln = 4 * (int)b + j, ch = 4 * pc.quad + j;
                     p->melMeta[4 * ln + 0] = r0[b];
+                    if (pc.quad < 0) continue;
                     p->melMeta[4 * ln + 1] = (pc.pos >= 1 ? 1 : 0) | (owner ? 2 : 0) | (pc.pos >= 2 ? 4 : 0) | (pc.pos >= 3 ? 8 : 0);
                     p->melMeta[4 * ln + 2] = (owner && ch < P) ? ch : -1;
                     if (ch >= P) continue;
@@ -555,19 +577,44 @@ static int choose_tile(MFCCPlan *p)
     p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
     // Lean instantiation: mono 16-bit input, one row, even frame shift, none of the per-frame extras.
     p->mode = (leanCand && (pplog == 3 || pplog == 4) && bestTab) ? (p->melSteps > 0 ? 2 : 1) : 0;
-    // The pipelined kernel for 256 complex points (lean256.hip) keeps only the cepstral table and the
-    // mel weights in the shared part of the LDS and has no staging area for finished rows.
-    p->lean256 = p->mode == 2 && useTeams == 4 && lean256_applies(log2nc, p->mode, bestFt, c->cfg.inc, c->cfg.wlen);
-    if (p->lean256) {
-        p->tabElems = (c->dctElems + kMelSteps * 64 + 3) & ~3;
-        p->featElems = 0;
-        p->teamElems = p->rowPitch + p->rawOrZElems + p->fbkElems + 16;
-        p->ldsBytes = ((size_t)p->tabElems + 4 * (size_t)p->teamElems) * sizeof(float);
-        p->blocksPerCu = (int)std::max<size_t>(1, std::min<size_t>(2, kLds / ((p->ldsBytes + 4095) & ~(size_t)4095)));
-        if (getenv("MFCC_DEBUG"))
-            fprintf(stderr, "mfcc plan: pipelined 256-point kernel, framesPerTile %d, LDS %zu B, workgroups/CU %d\n", bestFt,
-                    p->ldsBytes, p->blocksPerCu);
-        return MFCC_OK;
+    // The pipelined kernel for 256 complex points (lean256.hip): a wave is a team and a tile one
+    // round of 4 frames; the shared part of the LDS holds the cepstral table, the mel weights and
+    // the window pairs; a wave's region holds its sample row and four work areas.  12 waves per
+    // workgroup when the registers and the LDS allow, else 8; one workgroup per CU.
+    p->lean256 = false;
+    if (p->mode == 2 && p->totalRows < 0x7fffffffLL && c->cfg.wlen >= 8 && lean256_applies(log2nc, p->mode, c->cfg.inc, c->cfg.wlen, p->melSteps)) {
+        const int nz = lean256_nz(c->cfg.wlen);
+        const int ft = 4;
+        const int ninst = (ft - 1) * c->cfg.inc + c->cfg.wlen + 1;
+        // the row ends where the last frame's zero-window reads and the last fetched vector end
+        const int rowPitchL = (std::max((ft - 1) * c->cfg.inc + 32 * nz, ((ninst + 7) & ~7)) + 3) & ~3;
+        // work area of a frame: its padded complex points only, frame slots 8 banks apart
+        const int zl = ((2 * (nc + nc / 16) + 23) & ~31) + 8;
+        const int teamL = rowPitchL + 4 * zl;
+        const int tabL = (((c->dctElems + 1) & ~1) + lean256_mel_steps(p->melSteps) * 64 + 2 * nz * 16 + nc + 3) & ~3;
+        for (int pass = 0; pass < 2 && !p->lean256; ++pass) {
+            const int waves = lean256_waves(c->cfg.wlen, pass == 0);
+            if (pass == 1 && waves == lean256_waves(c->cfg.wlen, true)) break;
+            const size_t bytes = ((size_t)tabL + (size_t)waves * teamL) * sizeof(float);
+            if (bytes > kLds) continue;
+            p->lean256 = true;
+            p->leanWaves = waves;
+            p->framesPerTile = ft;
+            p->rowPitch = rowPitchL;
+            p->rowTail = 0;
+            p->rawOrZElems = 4 * zl;
+            p->zPitch = zl;
+            p->fbkElems = 0;
+            p->featElems = 0;
+            p->teamElems = teamL;
+            p->tabElems = tabL;
+            p->activeTeams = waves;
+            p->ldsBytes = bytes;
+            p->blocksPerCu = 1;
+            if (getenv("MFCC_DEBUG"))
+                fprintf(stderr, "mfcc plan: pipelined 256-point kernel, %d waves per workgroup, LDS %zu B\n", waves, bytes);
+        }
+        if (p->lean256) return MFCC_OK;
     }
     const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->mode, p->ldsBytes);
     if (getenv("MFCC_DEBUG"))
@@ -619,6 +666,19 @@ static int finish_plan(MFCCPlan *p)
             const uint64_t off = (uint64_t)(d.byteOff + first0 * bpi);
             if (off > kTileOffMask) return set_error("PCM buffer larger than 2^48 bytes"), MFCC_E_ARG;
             TileDesc td;
+            if (p->lean256) {
+                // k_lean256's form: offset of the first sample itself; bit 60: it starts the signal;
+                // bit 61: a 16-byte vector of the fetch (which begins one sample earlier) would
+                // leave the planned bytes
+                const int64_t src = d.byteOff + first * bpi;
+                const int64_t vecs = ((int64_t)(nf - 1) * c->cfg.inc + c->cfg.wlen + 1 + 7) / 8;
+                const bool edge = src - bpi < 0 || src - bpi + vecs * 16 > planEnd;
+                if ((uint64_t)src > kTileOffMask) return set_error("PCM buffer larger than 2^48 bytes"), MFCC_E_ARG;
+                td.src = (uint64_t)src | ((uint64_t)nf << 48) | ((uint64_t)(first > 0 ? 0 : 1) << 60) | ((uint64_t)(edge ? 1 : 0) << 61);
+                td.outRow = d.outRow + f0;
+                tileDesc.push_back(td);
+                continue;
+            }
             td.src = off | ((uint64_t)nf << 48) | ((uint64_t)(first > 0 ? 1 : 0) << 60);
             if (p->mode == 2 && first > 0) {
                 const int64_t elems = (int64_t)(nf - 1) * c->cfg.inc + c->cfg.wlen + 1; // with the predecessor
@@ -1002,10 +1062,12 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     if constexpr (sizeof(T) == 4) {
         if (p->lean256) {
             // every wave takes a contiguous run of tiles
+            const int waves = p->activeTeams;
+            const int nb = (int)std::min<int64_t>((p->numTiles + waves - 1) / waves, (int64_t)p->numCus * p->blocksPerCu);
             a.numUtts = p->numUtts;
             a.planEnd = p->planEnd;
-            a.tilesPerTeam = (p->numTiles + blocks * 4 - 1) / (blocks * 4);
-            const int rcl = launch_lean256(a, blocks, p->ldsBytes, stream);
+            a.tilesPerTeam = (p->numTiles + nb * waves - 1) / (nb * waves);
+            const int rcl = launch_lean256(a, nb, p->ldsBytes, p->leanWaves, stream);
             if (rcl) return set_error("static-feature kernel launch failed (HIP error %d)", rcl), MFCC_E_DEVICE;
             return MFCC_OK;
         }

@@ -166,10 +166,12 @@ __device__ __forceinline__ Acc4<double> mfma16(double a, double b, Acc4<double> 
 
 template <typename T>
 __device__ __forceinline__ T tlog(T x);
-// single precision: hardware log2 times ln 2 (absolute error below 1e-5 for the values that
-// occur here, |ln x| < 50), an order of magnitude inside the 1e-4 log-mel tolerance
+// single precision: the hardware log2 instruction times ln 2 (absolute error below 1e-5 for the
+// values that occur here, |ln x| < 50, an order of magnitude inside the 1e-4 log-mel tolerance).
+// Its arguments are filterbank sums >= 1 and frame energies of integer samples, never denormal
+// (0 gives -inf as log does), so the library routine's rescaling of denormals is left out.
 template <>
-__device__ __forceinline__ float tlog<float>(float x) { return __logf(x); }
+__device__ __forceinline__ float tlog<float>(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 template <>
 __device__ __forceinline__ double tlog<double>(double x) { return log(x); }
 template <typename T>

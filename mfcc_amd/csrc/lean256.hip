@@ -2,185 +2,182 @@
 // frames of at most 512 samples (256 complex points), log-mel filterbank or cepstra (+ C0, + log
 // energy), single precision.  Same arithmetic as k_front's matrix-core mode (Ham main.c:229,
 // Wave2FBank mfcc.c:125-177, FBank2MFCC / FBank2C0 mfcc.c:180-208, row layout main.c:241-249),
-// organised as a software pipeline so that a wave never waits for memory it could have asked for
-// earlier:
-//   - every wave owns a CONTIGUOUS range of tiles and derives each tile's geometry from the
-//     utterance table with scalar arithmetic (no per-tile descriptor load);
-//   - a tile's raw samples are requested one whole tile ahead (16-byte vectors into registers) and
-//     expanded into the LDS sample row during the previous tile's last round, right after that
-//     round has fetched its own samples;
-//   - a round's sample pairs are requested before the mel phase of the round before it;
-//   - results go from registers straight to global memory (no staging, no alignment cases).
+// organised for occupancy and as a software pipeline:
+//   - a wave is a team of its own (4 frames in flight, 16 lanes x 16 points each) and a workgroup
+//     is up to 12 of them, three per SIMD, so that the vector units stay busy while other waves
+//     wait for LDS round trips.  To fit that many, the per-lane tables a wave re-reads every round
+//     (window, mel weights) sit in LDS, shared by the workgroup, and only twiddles and split
+//     factors stay in registers;
+//   - a tile is one round (4 consecutive frames of one utterance); every wave owns a CONTIGUOUS
+//     range of tiles and reads their host-resolved 16-byte descriptors through the scalar data
+//     path, three tiles ahead, so the tile loop carries no index arithmetic;
+//   - a tile's raw samples are requested one whole round ahead (16-byte vectors into registers)
+//     and expanded into the LDS sample row right after the round before it has read its own
+//     samples; tiles at the first or last bytes of the buffer fetch sample by sample instead
+//     (the only special case: the arithmetic is the same for every tile);
+//   - results go from registers straight to global memory, one round late (see flush below).
 #include <hip/hip_runtime.h>
 
 #include "front_util.h"
+#include "stamps.h"
 
 namespace mfcc {
 
 namespace {
 
-constexpr int kLeanNc = 256, kLeanG = 16, kLeanPpl = 16, kLeanGt = 4, kLeanPfn = 3;
+constexpr int kLeanNc = 256, kLeanG = 16, kLeanPpl = 16, kLeanGt = 4, kLeanPfn = 2;
 
 typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
+typedef unsigned int u4s __attribute__((ext_vector_type(4)));
 
-// One tile as the pipeline sees it (all wave-uniform).
+// One tile as the pipeline sees it (all wave-uniform): the two 64-bit words of its TileDesc.
+//   w0, w1 & 0xffff: byte offset of the tile's first sample inside the PCM buffer
+//   w1 bits 16..19:  frames (0: no tile)
+//   w1 bit 28:       the tile starts the signal (first-sample rule of PreEmphasise)
+//   w1 bit 29:       a 16-byte vector of its fetch would leave the planned PCM bytes
 struct LeanTile {
-    unsigned long long src; // byte offset of the predecessor of the first sample (or of that sample)
-    long long outRow;       // output row of the tile's first frame
-    int nf;                 // frames (0: no tile)
-    int hasPrev;            // the first sample has a predecessor inside the buffer
-    int direct;             // raw samples may be fetched as kLeanPfn 16-byte vectors per lane
-};
-
-// Walks the tiles of the batch in order: utterance u, tile j of it.
-struct LeanIter {
-    int u, j, nt;           // nt: tiles of utterance u
-    long long byteOff, outRow;
-    int numFrames, lead;
+    unsigned w0, w1;
+    int outRow;
+    __device__ __forceinline__ int nf() const { return (int)((w1 >> 16) & 15u); }
+    __device__ __forceinline__ bool first() const { return (w1 >> 28) & 1u; }
+    __device__ __forceinline__ bool edge() const { return (w1 >> 29) & 1u; }
+    __device__ __forceinline__ long long src() const { return (long long)(((unsigned long long)(w1 & 0xffffu) << 32) | w0); }
 };
 
 __device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
-__device__ __forceinline__ long long sgpr64(long long x)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x & 0xffffffffll));
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)x >> 32));
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
 
-__device__ __forceinline__ void lean_load_utt(LeanIter &it, const FrontArgs<float> &a, int u)
+// Descriptor `idx` of the wave's range through the scalar data path (the table is read-only for
+// the whole launch and the index is wave-uniform).
+__device__ __forceinline__ LeanTile lean_desc(const TileDesc *tab, int idx, bool valid)
 {
-    const UttDesc *d = a.utts + u;
-    it.u = u;
-    it.j = 0;
-    it.byteOff = sgpr64(d->byteOff);
-    it.outRow = sgpr64(d->outRow);
-    it.numFrames = sgpr(d->numFrames);
-    it.lead = sgpr(d->lead);
-    it.nt = (it.numFrames + a.framesPerTile - 1) / a.framesPerTile;
-}
-
-__device__ __forceinline__ LeanTile lean_tile(const LeanIter &it, const FrontArgs<float> &a, bool valid)
-{
-    LeanTile t;
-    const int f0 = it.j * a.framesPerTile;
-    t.nf = valid ? min(a.framesPerTile, it.numFrames - f0) : 0;
-    const long long first = (long long)f0 * a.inc + it.lead; // first instant of the first frame
-    t.hasPrev = first > 0 ? 1 : 0;
-    t.src = (unsigned long long)(it.byteOff + (first - t.hasPrev) * 2);
-    t.outRow = it.outRow + f0;
-    const int vecs = ((t.nf - 1) * a.inc + a.wlen + 1 + 7) >> 3; // 8 samples each, predecessor included
-    t.direct = (valid && t.hasPrev && vecs <= kLeanPfn * 64 && (long long)t.src + (long long)vecs * 16 <= a.planEnd) ? 1 : 0;
+    LeanTile t = {0u, 0u, 0};
+    if (valid) {
+        typedef const __attribute__((address_space(4))) u4s *cptr;
+        const u4s d = reinterpret_cast<cptr>(reinterpret_cast<unsigned long long>(tab))[idx];
+        t.w0 = d.x;
+        t.w1 = d.y;
+        t.outRow = (int)d.z;
+    }
     return t;
 }
 
-// Moves to the next tile of the batch (utterances without frames are skipped).  The caller
-// bounds the walk by its tile count, so the utterance index stays inside the table.
-__device__ __forceinline__ void lean_advance(LeanIter &it, const FrontArgs<float> &a)
+// lane i takes x of lane i + 1; lane 63 takes `last`
+__device__ __forceinline__ unsigned wave_shl1(unsigned x, unsigned last)
 {
-    if (++it.j < it.nt) return;
-    int u = it.u + 1;
-    while (u < a.numUtts) {
-        lean_load_utt(it, a, u);
-        if (it.nt > 0) return;
-        ++u;
-    }
-    it.u = a.numUtts;
-    it.j = 0;
-    it.nt = 0;
+    return (unsigned)__builtin_amdgcn_update_dpp((int)last, (int)x, 0x130, 0xf, 0xf, false);
 }
 
 } // namespace
 
 // NZ: number of first-stage inputs of a lane that can be non-zero, ceil(wlen / 32): 13 for
 // 400-sample frames in 512 points (the zero padding of mfcc.c:144-147 is then never loaded,
-// multiplied or added), 16 otherwise.
-template <int NZ>
-__global__ __launch_bounds__(kBlock, 2) void k_lean256(const FrontArgs<float> a)
+// multiplied or added), 16 otherwise.  WAVES: waves (teams) per workgroup.  MSG: groups of 8 steps
+// of the mel filterbank products.
+template <int NZ, int WAVES, int MSG>
+__global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a)
 {
-    constexpr int NC = kLeanNc, G = kLeanG, PPL = kLeanPpl, GT = kLeanGt, TEAM = 64, PFN = kLeanPfn;
+    constexpr int NC = kLeanNc, G = kLeanG, PPL = kLeanPpl, GT = kLeanGt, TEAM = 64, NT = WAVES * 64;
+    constexpr int PFN = kLeanPfn, MS = MSG * 8;
+    constexpr bool SWL = WAVES > 8; // three waves per SIMD: the split factors are read from LDS too
     typedef float T;
+    STAMP_DECL
+    STAMP_START;
     const int tid = threadIdx.x;
     const int wave = sgpr(tid >> 6);
     const int tt = tid & 63, l = tt & (G - 1), grp = tt >> 4;
 
+    // LDS: [cepstral table | mel weights (MS x 64) | window pairs (NZ x 16) | split factors (128)] then one region per
+    // wave: [sample row | GT work areas (the tile's log-mel rows alias the first in cepstral mode)]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *ldsTab = reinterpret_cast<T *>(smem);             // cepstral table (dctElems), mel weights
-    T *rows = ldsTab + a.tabElems + wave * a.teamElems;  // pre-emphasised samples of the tile
-    T *zbuf = rows + a.rowPitch;                         // GT work areas; raw PCM bytes alias it
-    T *fbk = zbuf + a.rawOrZElems;                       // framesPerTile x P log-mel values (cepstral mode)
-    unsigned *raw = reinterpret_cast<unsigned *>(zbuf);
+    T *ldsTab = reinterpret_cast<T *>(smem);
+    T *melWl = ldsTab + ((a.dctElems + 1) & ~1);
+    cpx<T> *winl = reinterpret_cast<cpx<T> *>(melWl + MS * 64);
+    T *rows = ldsTab + a.tabElems + wave * a.teamElems;
+    T *zbuf = rows + a.rowPitch;
+    T *fbk = zbuf;
 
-    for (int i = tid; i < a.dctElems; i += kBlock) ldsTab[i] = a.dctT[i];
+    for (int i = tid; i < a.dctElems; i += NT) ldsTab[i] = a.dctT[i];
+    for (int i = tid; i < MS * 64; i += NT) melWl[i] = i < a.melSteps * 64 ? a.melW[i] : 0.0f;
+    for (int i = tid; i < NZ * 16; i += NT) winl[i] = reinterpret_cast<const cpx<T> *>(a.window)[i]; // half the Hamming values
+    cpx<T> *swl = winl + NZ * 16;
+    for (int i = tid; i < NC / 2; i += NT) swl[i] = reinterpret_cast<const cpx<T> *>(a.splitTw)[i];
+    // Everything a frame reads from the row is finite from here on: a tile only overwrites it with
+    // converted samples, and what lies behind a frame's last sample meets a zero window value.
+    for (int s = tt; s < a.rowPitch; s += TEAM) rows[s] = (T)0;
+    __syncthreads();
     const T *dctT = ldsTab;
+    const T *melB = melWl + tt;
+    const cpx<T> *winp = winl + l; // pair r of the lane: winp[16 r]
 
-    // Per-lane constants: window pairs (half the Hamming values), split factors, second-stage twiddles.
-    cpx<T> wreg[NZ];
+    // Per-lane constants in registers: split factors, second-stage twiddles.
     cpx<T> swreg[PPL / 2];
     cpx<T> twr[fft_twiddle_regs<8, 4>()];
 #pragma unroll
-    for (int r = 0; r < NZ; ++r) wreg[r] = *reinterpret_cast<const cpx<T> *>(a.window + 2 * (l + G * r));
-#pragma unroll
-    for (int q = 0; q < PPL / 2; ++q) swreg[q] = reinterpret_cast<const cpx<T> *>(a.splitTw)[l + G * q];
+    for (int q = 0; q < PPL / 2; ++q) swreg[q] = SWL ? cpx<T>{0, 0} : reinterpret_cast<const cpx<T> *>(a.splitTw)[l + G * q];
     fft_load_twiddles<T, 8, 4>(twr, l, reinterpret_cast<const cpx<T> *>(a.tw));
-    // mel weights: [step][lane] behind the cepstral table, shared by the workgroup's waves
-    T *melWl = ldsTab + a.dctElems;
-    for (int i = tid; i < kMelSteps * 64; i += kBlock) melWl[i] = i < a.melSteps * 64 ? a.melW[i] : 0.0f;
-    __syncthreads();
-    const T *melB = melWl + tt;
     const int4 mm = reinterpret_cast<const int4 *>(a.melMeta)[tt];
     const T *melA = zbuf + (tt & 3) * a.zPitch + mm.x;
     const int melFlags = mm.y, melCh = mm.z;
+    const float chain1 = (melFlags & 1) ? 1.0f : 0.0f, chain2 = (melFlags & 4) ? 1.0f : 0.0f, chain3 = (melFlags & 8) ? 1.0f : 0.0f;
     const float kf = (float)a.preK;
     const int JW = a.M + a.c0Flag;
 
     // The wave's tile range.
-    const int teamId = blockIdx.x * (kBlock / TEAM) + wave;
+    const int teamId = blockIdx.x * WAVES + wave;
     const int t0 = teamId * a.tilesPerTeam;
-    int count = min(a.numTiles, t0 + a.tilesPerTeam) - t0;
-    if (count <= 0) return;
-    LeanIter it;
-    {
-        // largest u with tileBegin[u] <= t0 (tileBegin is the running tile count, so among equal
-        // values only the last utterance has tiles)
-        int lo = 0, hi = a.numUtts - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (sgpr(a.utts[mid].tileBegin) <= t0) lo = mid;
-            else hi = mid - 1;
-        }
-        lean_load_utt(it, a, lo);
-        it.j = t0 - sgpr(a.utts[lo].tileBegin);
+    const int count = min(a.numTiles, t0 + a.tilesPerTeam) - t0;
+    if (count <= 0) {
+        STAMP_FLUSH;
+        return;
     }
-    LeanTile cur = lean_tile(it, a, true);
-    lean_advance(it, a);
-    LeanTile nx = lean_tile(it, a, count > 1);
-    if (count > 1) lean_advance(it, a);
-    LeanTile nn = lean_tile(it, a, count > 2);
+    const TileDesc *tab = a.tiles + t0;
+    LeanTile cur = lean_desc(tab, 0, true);
+    LeanTile nx = lean_desc(tab, 1, count > 1);
+    LeanTile nn = lean_desc(tab, 2, count > 2);
 
     u4u pf[PFN];
 #pragma unroll
     for (int j = 0; j < PFN; ++j) pf[j] = u4u{0u, 0u, 0u, 0u};
 
+    // 16-byte vectors a tile's fetch covers: 8 samples each, the predecessor of the first included
+    auto tile_vecs = [&](const LeanTile &t) { return ((t.nf() - 1) * a.inc + a.wlen + 1 + 7) >> 3; };
     // Requests the raw samples of tile t (vector j of lane tt = raw samples 8 (tt + 64 j) ..
     // + 7, sample 0 being the predecessor of the tile's first sample).
     auto fetch = [&](const LeanTile &t) {
-        const int nvec = ((t.nf - 1) * a.inc + a.wlen + 1 + 7) >> 3;
-        const u4u *g = reinterpret_cast<const u4u *>(a.pcm + t.src);
-#pragma unroll
-        for (int j = 0; j < PFN; ++j)
-            if (tt + j * TEAM < nvec) pf[j] = g[tt + j * TEAM];
-    };
-    // Fetched vectors -> pre-emphasised row: row[s] = raw[s + 1] - k raw[s] (PreEmphasise, call
-    // site main.c:208), the vector's last output taking raw[8 j + 8] from the next lane.  Values
-    // behind the tile's last sample are finite and zeroed by the tail fill below.
-    auto expand = [&](const LeanTile &t) {
-        const int nvec = ((t.nf - 1) * a.inc + a.wlen + 1 + 7) >> 3;
+        const int nvec = tile_vecs(t);
+        const long long off0 = t.src() - 2;
+        // Tiles at the first or last bytes of the buffer keep every vector inside it by clamping
+        // its offset (expand() then redoes such a tile's samples one by one).
+        int lo = 0, hi = 0x7ffffff0;
+        if (t.edge()) {
+            lo = (int)(off0 < 0 ? -off0 : 0);
+            hi = (int)min(a.planEnd - 16 - off0, (long long)hi);
+        }
+        const unsigned char *g = a.pcm + off0;
 #pragma unroll
         for (int j = 0; j < PFN; ++j) {
             const int vj = tt + j * TEAM;
-            unsigned nxw = (unsigned)__shfl_down((int)pf[j].x, 1, 64);
-            const unsigned wrap = j + 1 < PFN ? (unsigned)__shfl((int)pf[j + 1 < PFN ? j + 1 : j].x, 0, 64) : 0u;
-            nxw = tt == 63 ? wrap : nxw;
+            if (vj < nvec) pf[j] = *reinterpret_cast<const u4u *>(g + min(max(16 * vj, lo), hi));
+        }
+    };
+    // Raw sample i of tile t (0: the predecessor of its first sample) for the one-by-one path:
+    // zero outside the planned bytes.
+    auto raw_checked = [&](const LeanTile &t, int i) {
+        const long long b = t.src() - 2 + 2ll * i;
+        int sv = 0;
+        if (b >= 0 && b + 2 <= a.planEnd) sv = (int)(short)((unsigned)a.pcm[b] | ((unsigned)a.pcm[b + 1] << 8));
+        return (float)sv;
+    };
+    // Fetched vectors -> pre-emphasised row: row[s] = raw[s + 1] - k raw[s] (PreEmphasise, call
+    // site main.c:208), the vector's last output taking raw[8 j + 8] from the next lane; the
+    // signal's first sample becomes (1 - k) raw[1].
+    auto expand = [&](const LeanTile &t) {
+        const int nvec = tile_vecs(t);
+#pragma unroll
+        for (int j = 0; j < PFN; ++j) {
+            const int vj = tt + j * TEAM;
+            const unsigned wrap = j + 1 < PFN ? (unsigned)sgpr((int)pf[j + 1 < PFN ? j + 1 : j].x) : 0u;
+            const unsigned nxw = wave_shl1(pf[j].x, wrap);
             if (vj < nvec) {
                 const unsigned d[5] = {pf[j].x, pf[j].y, pf[j].z, pf[j].w, nxw};
                 float sm[9];
@@ -195,60 +192,18 @@ __global__ __launch_bounds__(kBlock, 2) void k_lean256(const FrontArgs<float> a)
                 *reinterpret_cast<float4 *>(dstRow + 4) = make_float4(y[4], y[5], y[6], y[7]);
             }
         }
-    };
-    // Tiles that cannot take the vector path (an utterance's first tile, the last bytes of the
-    // buffer) go through a copy of their bytes in LDS.  Rare, and synchronous.  First tiles:
-    // aligned 16-byte loads, samples picked at run-time byte offsets, double arithmetic.
-    auto expand_general = [&](const LeanTile &t) {
-        const int ns = (t.nf - 1) * a.inc + a.wlen;
-        const double mean[4] = {0, 0, 0, 0};
-        if (t.hasPrev) {
-            // the last bytes of the buffer: exactly the tile's bytes (16-byte vectors from the
-            // possibly unaligned start, the rest byte by byte), then the arithmetic of the vector path
-            const unsigned char *g0 = a.pcm + t.src;
-            const int nbytes = (ns + 1) * 2, nfull = nbytes >> 4;
-            for (int i = tt; i < nfull; i += TEAM) {
-                const u4u v4 = reinterpret_cast<const u4u *>(g0)[i];
-                reinterpret_cast<uint4 *>(raw)[i] = make_uint4(v4.x, v4.y, v4.z, v4.w);
-            }
-            for (int i = (nfull << 4) + tt; i < nbytes; i += TEAM) reinterpret_cast<unsigned char *>(raw)[i] = g0[i];
-            team_sync<TEAM>();
-            unpack_tile_fast<T, false, 1, 2, TEAM>(rows, raw, a.rowPitch, 1, ns, mean, a.preK, tt);
-            team_sync<TEAM>();
-            return;
+        if (t.edge()) {
+            const int ns = (t.nf() - 1) * a.inc + a.wlen;
+            for (int sIdx = tt; sIdx < ns; sIdx += TEAM) rows[sIdx] = raw_checked(t, sIdx + 1) - kf * raw_checked(t, sIdx);
         }
-        const unsigned long long gaddr = reinterpret_cast<unsigned long long>(a.pcm + t.src);
-        const int gmis = (int)(gaddr & 15ull);
-        const uint4 *src = reinterpret_cast<const uint4 *>(gaddr - gmis);
-        const int nvec = (gmis + (ns + t.hasPrev) * 2 + 15) >> 4;
-        for (int i = tt; i < nvec; i += TEAM) reinterpret_cast<uint4 *>(raw)[i] = src[i];
-        team_sync<TEAM>();
-        unpack_tile<T, true, 1, TEAM>(rows, raw, a.rowPitch, 1, 2, gmis, t.hasPrev, ns, mean, a.preK, tt);
-        team_sync<TEAM>();
-    };
-    auto tail_fill = [&](const LeanTile &t) {
-        const int ns = (t.nf - 1) * a.inc + a.wlen;
-        for (int s = tt; s < a.rowTail; s += TEAM) rows[ns + s] = (T)0;
-    };
-    // Sample pairs (2n, 2n+1), n = l + 16 r, of frame `fr` of the tile in the row.
-    cpx<T> xpre[NZ];
-    auto request = [&](int fr) {
-        const cpx<T> *xp = reinterpret_cast<const cpx<T> *>(rows + fr * a.inc + 2 * l);
-#pragma unroll
-        for (int r = 0; r < NZ; ++r) xpre[r] = xp[r * (NC / 16)];
+        if (t.first() && tt == 0) rows[0] = (float)((double)raw_checked(t, 1) * (1.0 - a.preK));
     };
 
-    // Prologue: the first tile's row, the second tile's fetch, the first round's samples.
-    if (cur.direct) {
-        fetch(cur);
-        expand(cur);
-    } else {
-        expand_general(cur);
-    }
-    tail_fill(cur);
-    if (nx.direct) fetch(nx);
+    // Prologue: the first tile's row, the second tile's fetch.
+    fetch(cur);
+    expand(cur);
+    if (nx.nf() > 0) fetch(nx);
     team_sync<TEAM>();
-    request(grp < cur.nf ? grp : 0);
 
     // Results of a round are written one round later, behind the point where the next tile's fetched
     // vectors are expanded: that point waits for every older memory operation, and the newest store
@@ -262,29 +217,34 @@ __global__ __launch_bounds__(kBlock, 2) void k_lean256(const FrontArgs<float> a)
             if (a.fbankFlag && (melFlags & 2) && melCh >= 0) {
 #pragma unroll
                 for (int r = 0; r < GT; ++r)
-                    if (r < dCount) ob[(long long)r * a.step + melCh] = dlv[r];
+                    if (r < dCount) ob[r * a.step + melCh] = dlv[r];
             }
-            if (a.energyFlag && l == 0 && grp < dCount) ob[(long long)grp * a.step + JW] = dte; // main.c:243
+            if (a.energyFlag && l == 0 && grp < dCount) ob[grp * a.step + JW] = dte; // main.c:243
             dCount = 0;
         }
     };
 
-    for (;;) {
-        const int nf = cur.nf;
-        float *outBase = a.out + cur.outRow * a.step;
-        for (int base = 0; base < nf; base += GT) {
-            const int item = base + grp;
-            const bool active = item < nf;
-            const bool last = base + GT >= nf;
+    for (int ti = 0;; ++ti) {
+        const LeanTile d3 = lean_desc(tab, ti + 3, ti + 3 < count);
+        const int nf = cur.nf();
+        {
+            STAMP(0);
             T *Zt = zbuf + grp * a.zPitch;
             cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
 
-            // ---- window (Ham main.c:229), frame energy (te, mfcc.c:138-142)
+            // ---- sample pairs (2n, 2n+1), n = l + 16 r, times the window (Ham main.c:229); frame
+            //      energy (te, mfcc.c:138-142).  Slots past the tile's last frame redo frame 0.
             cpx<T> v[PPL];
+            {
+                const cpx<T> *xp = reinterpret_cast<const cpx<T> *>(rows + (grp < nf ? grp : 0) * a.inc + 2 * l);
+                cpx<T> xs[NZ], ws[NZ];
+                lds_read_strided<NZ, 128>(xs, xp);
+                lds_read_strided<NZ, 128>(ws, winp);
 #pragma unroll
-            for (int r = 0; r < NZ; ++r) v[r] = xpre[r] * wreg[r];
+                for (int r = 0; r < NZ; ++r) v[r] = xs[r] * ws[r];
 #pragma unroll
-            for (int r = NZ; r < PPL; ++r) v[r] = cpx<T>{0.0f, 0.0f};
+                for (int r = NZ; r < PPL; ++r) v[r] = cpx<T>{0.0f, 0.0f};
+            }
             T te = 0;
             if (a.energyFlag) {
                 cpx<T> e2 = {0, 0};
@@ -293,23 +253,25 @@ __global__ __launch_bounds__(kBlock, 2) void k_lean256(const FrontArgs<float> a)
                 te = group_sum<T, G>((T)4 * (e2.x + e2.y), nullptr, tt); // (half-scaled window)
             }
 
+            STAMP(1);
             // ---- the row is free once every lane holds its samples: next tile's row
-            if (last && nx.nf > 0) {
+            if (nx.nf() > 0) {
                 team_sync<TEAM>();
-                if (nx.direct) expand(nx);
-                else expand_general(nx);
-                tail_fill(nx);
-                if (nn.direct) fetch(nn);
+                expand(nx);
+                if (nn.nf() > 0) fetch(nn);
             }
             flush();
+            STAMP(2);
 
             // ---- 256-point complex FFT of z[n] = x[2n] + i x[2n+1] (Realft mfcc.c:262-270), last
             //      stage in registers: v[r] = Z[l + 16 r]
             fft_stages<T, 8, 4, 0, 0, false, true, 0, true>(v, Z, l, nullptr, twr);
+            STAMP(3);
 
             // ---- real-FFT split and power (mfcc.c:274-290, ek of mfcc.c:153-155): Z[256 - k] for
             //      k = l + 16 q is register 15 - q of lane 16 - l (own register 16 - q in lane 0)
             T pa[PPL / 2], pb[PPL / 2];
+            if constexpr (SWL) lds_read_strided<PPL / 2, 128>(swreg, swl + l);
 #pragma unroll
             for (int q = 0; q < PPL / 2; ++q) {
                 const cpx<T> hi = v[PPL - 1 - q], own = v[(PPL - q) & (PPL - 1)];
@@ -333,19 +295,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_lean256(const FrontArgs<float> a)
                 Zt[k2] = pb[q];
             }
             team_sync<TEAM>();
+            STAMP(4);
 
             // ---- mel filterbank (mfcc.c:152-163) as 4 x 4 x 1 matrix-core products: block b = 4
             //      lanes owns 4 consecutive channels and a run of bins; lane (b, i) feeds the power
             //      of frame slot i at bin r0_b + t and the weight of that bin for channel 4 q_b + i
-            // (loads of 8 steps run two groups ahead of the products that use them)
-            static_assert(kMelSteps == 32, "four groups of 8 steps");
-            float av[4][8], bw[4][8];
+            //      (loads of 8 steps run a group ahead of the products that use them)
+            float av[2][8], bw[2][8];
             Acc4<float> macc = {0, 0, 0, 0}, macc2 = {0, 0, 0, 0};
-            auto mel_load = [&](int c) {
+            auto mel_load = [&](int c, int g) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    av[c][t] = melA[8 * c + t];
-                    bw[c][t] = melB[(8 * c + t) * 64];
+                    av[c][t] = melA[8 * g + t];
+                    bw[c][t] = melB[(8 * g + t) * 64];
                 }
             };
             auto mel_mac = [&](int c) {
@@ -355,115 +317,125 @@ __global__ __launch_bounds__(kBlock, 2) void k_lean256(const FrontArgs<float> a)
                     macc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c][t + 1], bw[c][t + 1], macc2, 0, 0, 0);
                 }
             };
-            mel_load(0);
-            mel_load(1);
-            __builtin_amdgcn_sched_barrier(0);
-            mel_mac(0);
-            mel_load(2);
-            __builtin_amdgcn_sched_barrier(0);
-            mel_mac(1);
-            mel_load(3);
-            // the next round's sample pairs (its row is ready: same tile, or expanded above)
-            if (!last) request(base + GT + grp < nf ? base + GT + grp : 0);
-            else if (nx.nf > 0) request(grp < nx.nf ? grp : 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mel_mac(2);
-            mel_mac(3);
+            mel_load(0, 0);
+#pragma unroll
+            for (int g = 0; g < MSG; ++g) {
+                if (g + 1 < MSG) mel_load((g + 1) & 1, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mel_mac(g & 1);
+            }
             macc += macc2;
+            STAMP(5);
             {
-                // a channel quad cut over up to 4 neighbouring blocks: the chain's last block adds the others
-                float o1[4], o2[4], o3[4];
+                // a channel quad cut over up to 4 neighbouring blocks of one row of 16 lanes: the
+                // chain's last block adds the others (row-wise lane shifts by 4, 8, 12)
+                float ms[4] = {macc[0], macc[1], macc[2], macc[3]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    o1[r] = __shfl_up(macc[r], 4, 64);
-                    o2[r] = __shfl_up(macc[r], 8, 64);
-                    o3[r] = __shfl_up(macc[r], 12, 64);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float sum = macc[r];
-                    sum += (melFlags & 1) ? o1[r] : 0.0f;
-                    sum += (melFlags & 4) ? o2[r] : 0.0f;
-                    sum += (melFlags & 8) ? o3[r] : 0.0f;
-                    macc[r] = sum;
+                    const int m = __builtin_bit_cast(int, ms[r]);
+                    const float o1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(m, 0x114, 0xf, 0xf, true));
+                    const float o2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(m, 0x118, 0xf, 0xf, true));
+                    const float o3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(m, 0x11C, 0xf, 0xf, true));
+                    macc[r] = fmaf(o3, chain3, fmaf(o2, chain2, fmaf(o1, chain1, ms[r])));
                 }
             }
+            if (!a.fbankFlag) team_sync<TEAM>(); // the log-mel rows alias the first work area
             if ((melFlags & 2) && melCh >= 0) { // owner of channel melCh: log(max(., 1)), mfcc.c:171-176
 #pragma unroll
                 for (int r = 0; r < GT; ++r) {
-                    const int it2 = base + r;
-                    if (it2 < nf) {
-                        const T lv = __logf(macc[r] < 1.0f ? 1.0f : macc[r]);
-                        dlv[r] = lv;
-                        if (!a.fbankFlag) fbk[it2 * a.P + melCh] = lv;
-                    }
+                    const T lv = tlog<T>(fmaxf(macc[r], 1.0f));
+                    dlv[r] = lv;
+                    if (!a.fbankFlag && r < nf) fbk[r * a.P + melCh] = lv;
                 }
             }
-            if (a.energyFlag) dte = __logf(te);
-            dOff = (cur.outRow + base) * (long long)a.step;
-            dCount = min(GT, nf - base);
+            if (a.energyFlag) dte = tlog<T>(te);
+            dOff = (long long)cur.outRow * a.step;
+            dCount = nf;
             team_sync<TEAM>(); // the work areas are free for the next round
+            STAMP(6);
         }
         if (!a.fbankFlag) {
             // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208) of the tile
             //      as 16 x 16 x 4 matrix-core products: lane (i, g) = (lane % 16, lane / 16) feeds
             //      fbk[item i][k0 + g] and dct[coefficient i][k0 + g] and holds the results of items
             //      4 g .. 4 g + 3 for coefficient i.  The table's row M is all ones (C0).
+            float *outBase = a.out + (long long)cur.outRow * a.step;
             const int i16 = tt & 15, g4 = tt >> 4;
-            for (int ib = 0; ib * 16 < nf; ++ib)
-                for (int jb = 0; jb * 16 < JW; ++jb) {
-                    const int itemA = ib * 16 + i16, jB = jb * 16 + i16;
-                    const T *fa = fbk + (itemA < nf ? itemA : 0) * a.P;
-                    const T *db = dctT + (jB < JW ? jB : 0) * a.dctPitch;
-                    Acc4<T> acc = {0, 0, 0, 0};
-                    for (int k0 = 0; k0 < a.P; k0 += 4) {
-                        const int k = k0 + g4;
-                        T fv = fa[k < a.P ? k : 0], bv = db[k];
-                        fv = (itemA < nf && k < a.P) ? fv : (T)0;
-                        bv = jB < JW ? bv : (T)0;
-                        acc = mfma16(fv, bv, acc);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int item = ib * 16 + 4 * g4 + r;
-                        if (item < nf && jB < JW) outBase[(long long)item * a.step + jB] = acc[r] * a.mfnorm;
-                    }
+            for (int jb = 0; jb * 16 < JW; ++jb) {
+                const int jB = jb * 16 + i16;
+                const T *fa = fbk + (i16 < nf ? i16 : 0) * a.P;
+                const T *db = dctT + (jB < JW ? jB : 0) * a.dctPitch;
+                Acc4<T> acc = {0, 0, 0, 0};
+                for (int k0 = 0; k0 < a.P; k0 += 4) {
+                    const int k = k0 + g4;
+                    T fv = fa[k < a.P ? k : 0], bv = db[k];
+                    fv = (i16 < nf && k < a.P) ? fv : (T)0;
+                    bv = jB < JW ? bv : (T)0;
+                    acc = mfma16(fv, bv, acc);
                 }
+                // items 4 g4 .. 4 g4 + 3: only g4 = 0 holds frames of a one-round tile
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (g4 == 0 && r < nf && jB < JW) outBase[r * a.step + jB] = acc[r] * a.mfnorm;
+            }
             team_sync<TEAM>();
         }
-        if (--count <= 0) break;
+        if (ti + 1 >= count) break;
         cur = nx;
         nx = nn;
-        if (count > 2) lean_advance(it, a);
-        nn = lean_tile(it, a, count > 2);
+        nn = d3;
     }
     flush();
+    STAMP_FLUSH;
 }
 
-bool lean256_applies(int log2nc, int mode, int framesPerTile, int inc, int wlen)
+// Geometry the host plans with: tiles of one round (4 frames), 12 waves per workgroup (8 when the
+// frame fills more than 13 of a lane's 16 first-stage inputs, or when 12 regions do not fit the
+// LDS), one workgroup per CU.
+int lean256_nz(int wlen) { return wlen <= 2 * 16 * 13 ? 13 : 16; }
+int lean256_waves(int wlen, bool fits12) { return (lean256_nz(wlen) == 13 && fits12) ? 12 : 8; }
+int lean256_mel_steps(int melSteps) { return ((melSteps + 7) / 8) * 8; }
+
+bool lean256_applies(int log2nc, int mode, int inc, int wlen, int melSteps)
 {
-    // the fetch of a full tile must fit kLeanPfn vectors per lane
-    const long vecs = ((long)(framesPerTile - 1) * inc + wlen + 1 + 7) >> 3;
-    return log2nc == 8 && mode == 2 && vecs <= kLeanPfn * 64;
+    // the fetch of a full tile must fit the vectors a lane holds
+    const long vecs = ((long)(kLeanGt - 1) * inc + wlen + 1 + 7) >> 3;
+    return log2nc == 8 && mode == 2 && vecs <= kLeanPfn * 64 && melSteps >= 1 && melSteps <= kMelSteps;
 }
 
-int launch_lean256(const FrontArgs<float> &a, int numBlocks, size_t lds, void *stream)
+template <int NZ, int WAVES, int MSG>
+static int launch_lean_t(const FrontArgs<float> &a, int numBlocks, size_t lds, hipStream_t st)
 {
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    static bool attrSet[16][2] = {};
+    static bool attrSet[16] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
-    const bool nz13 = a.wlen <= 2 * 16 * 13;
-    if (dev < 16 && !attrSet[dev][nz13]) {
-        const void *fn = nz13 ? reinterpret_cast<const void *>(&k_lean256<13>) : reinterpret_cast<const void *>(&k_lean256<16>);
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (dev >= 16 || !attrSet[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lean256<NZ, WAVES, MSG>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attrSet[dev][nz13] = true;
+        if (dev < 16) attrSet[dev] = true;
     }
-    if (nz13) hipLaunchKernelGGL((k_lean256<13>), dim3(numBlocks), dim3(kBlock), lds, st, a);
-    else hipLaunchKernelGGL((k_lean256<16>), dim3(numBlocks), dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((k_lean256<NZ, WAVES, MSG>), dim3(numBlocks), dim3(WAVES * 64), lds, st, a);
     return (int)hipGetLastError();
+}
+
+template <int NZ, int WAVES>
+static int launch_lean_w(const FrontArgs<float> &a, int numBlocks, size_t lds, hipStream_t st)
+{
+    switch ((a.melSteps + 7) / 8) {
+    case 1: return launch_lean_t<NZ, WAVES, 1>(a, numBlocks, lds, st);
+    case 2: return launch_lean_t<NZ, WAVES, 2>(a, numBlocks, lds, st);
+    case 3: return launch_lean_t<NZ, WAVES, 3>(a, numBlocks, lds, st);
+    default: return launch_lean_t<NZ, WAVES, 4>(a, numBlocks, lds, st);
+    }
+}
+
+int launch_lean256(const FrontArgs<float> &a, int numBlocks, size_t lds, int waves, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (lean256_nz(a.wlen) == 13) return waves == 12 ? launch_lean_w<13, 12>(a, numBlocks, lds, st) : launch_lean_w<13, 8>(a, numBlocks, lds, st);
+    return launch_lean_w<16, 8>(a, numBlocks, lds, st);
 }
 
 } // namespace mfcc

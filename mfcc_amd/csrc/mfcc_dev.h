@@ -43,7 +43,7 @@ constexpr uint64_t kTileOffMask = (1ull << 48) - 1;
 template <typename T>
 struct FrontArgs {
     const unsigned char *pcm;
-    const TileDesc *tiles;
+    const TileDesc *tiles;    // (k_lean256: its own encoding, see LeanTile in lean256.hip)
     const UttDesc *utts;      // read only for the row means (zeroMean != 0)
     const int32_t *tileUtt;   // utterance of each tile (read only if zeroMean != 0)
     int zeroMean;
@@ -145,8 +145,11 @@ struct StatArgs {
 int launch_front(int precision, int log2nc, int pplog, const void *args, int numBlocks,
                  size_t ldsBytes, void *stream);
 // lean256.hip: pipelined kernel for mono 16-bit, 256 complex points, matrix-core mel (mode 2 plans)
-bool lean256_applies(int log2nc, int mode, int framesPerTile, int inc, int wlen);
-int launch_lean256(const FrontArgs<float> &a, int numBlocks, size_t ldsBytes, void *stream);
+bool lean256_applies(int log2nc, int mode, int inc, int wlen, int melSteps);
+int lean256_nz(int wlen);                 // first-stage inputs per lane that can be non-zero (13 or 16)
+int lean256_waves(int wlen, bool fits12); // waves (teams) per workgroup
+int lean256_mel_steps(int melSteps);      // rows of the mel weight table the kernel keeps in LDS
+int launch_lean256(const FrontArgs<float> &a, int numBlocks, size_t ldsBytes, int waves, void *stream);
 bool front_variant_exists(int log2nc, int pplog); // pplog: log2 of complex points per lane (4, 3, 2)
 int front_groups(int log2nc, int pplog);          // frames in flight per workgroup
 int front_teams(int log2nc, int pplog);           // independent teams (tile streams) per workgroup
