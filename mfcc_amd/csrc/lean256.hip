@@ -61,6 +61,12 @@ __device__ __forceinline__ LeanTile lean_desc(const TileDesc *tab, int idx, bool
     return t;
 }
 
+// Work areas are 8 banks apart (pitch = 8 mod 32), which keeps the mel phase's 8 blocks x 4 slots
+// out of each other's banks; the frame of lane group g uses area slot_of(g) = {0, 2, 1, 3}, so that
+// the two groups whose power values one 32-lane pass stores sit 16 banks apart.  Result r of the
+// mel products therefore belongs to the tile's frame slot_of(r).
+__device__ __forceinline__ constexpr int slot_of(int g) { return ((g & 1) << 1) | (g >> 1); }
+
 // lane i takes x of lane i + 1; lane 63 takes `last`
 __device__ __forceinline__ unsigned wave_shl1(unsigned x, unsigned last)
 {
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
     constexpr int NC = kLeanNc, G = kLeanG, PPL = kLeanPpl, GT = kLeanGt, TEAM = 64, NT = WAVES * 64;
     constexpr int PFN = kLeanPfn, MS = MSG * 8;
     constexpr bool SWL = WAVES > 8; // three waves per SIMD: the split factors are read from LDS too
+    constexpr bool TREG = WAVES <= 8; // two waves per SIMD: window pairs and mel weights in registers
     typedef float T;
     STAMP_DECL
     STAMP_START;
@@ -115,6 +122,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
 #pragma unroll
     for (int q = 0; q < PPL / 2; ++q) swreg[q] = SWL ? cpx<T>{0, 0} : reinterpret_cast<const cpx<T> *>(a.splitTw)[l + G * q];
     fft_load_twiddles<T, 8, 4>(twr, l, reinterpret_cast<const cpx<T> *>(a.tw));
+    cpx<T> wreg[TREG ? NZ : 1];
+    float mwreg[TREG ? MS : 1];
+    if constexpr (TREG) {
+#pragma unroll
+        for (int r = 0; r < NZ; ++r) wreg[r] = reinterpret_cast<const cpx<T> *>(a.window)[l + G * r];
+#pragma unroll
+        for (int t = 0; t < MS; ++t) mwreg[t] = t < a.melSteps ? a.melW[t * 64 + tt] : 0.0f;
+    }
     const int4 mm = reinterpret_cast<const int4 *>(a.melMeta)[tt];
     const T *melA = zbuf + (tt & 3) * a.zPitch + mm.x;
     const int melFlags = mm.y, melCh = mm.z;
@@ -122,18 +137,69 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
     const float kf = (float)a.preK;
     const int JW = a.M + a.c0Flag;
 
-    // The wave's tile range.
-    const int teamId = blockIdx.x * WAVES + wave;
-    const int t0 = teamId * a.tilesPerTeam;
-    const int count = min(a.numTiles, t0 + a.tilesPerTeam) - t0;
-    if (count <= 0) {
+    // The wave's stream of tiles: chunks of a.tilesPerTeam consecutive tiles, the first one by the
+    // wave's index, every further one drawn from a counter the waves of the launch share (waves run
+    // at uneven speeds; fixed ranges left a fifth of the wave time idle at the end).  A chunk is
+    // drawn while the one before it is worked on.  a.work[0] is that counter, zero at launch; the
+    // last wave to finish (a.work[1] counts them) zeroes it again for the next launch.
+    const int teamId = blockIdx.x * WAVES + wave, numTeams = gridDim.x * WAVES, C = a.tilesPerTeam;
+    int chunkBase = teamId * C, chunkPos = 0, nextBase = 0;
+    bool haveNext = false, needDraw = true;
+    // A draw waits for its result, so it is made where the wave has just waited for all its memory
+    // operations anyway and before the next ones are issued (draw_step below, once per chunk).
+    auto draw = [&]() {
+        unsigned drawn = 0;
+        if (tt == 0) drawn = atomicAdd(a.work, 1u);
+        nextBase = (sgpr((int)drawn) + numTeams) * C;
+        haveNext = true;
+        needDraw = false;
+    };
+    // next tile of the stream, or -1 behind its end
+    auto next_tile = [&]() {
+        if (chunkPos == C) {
+            if (!haveNext) { // (only chunks of a single tile come here with the draw still to do)
+                if (!needDraw) return -1;
+                draw();
+            }
+            chunkBase = nextBase;
+            chunkPos = 0;
+            haveNext = false;
+            needDraw = chunkBase < a.numTiles;
+        }
+        const int id = chunkBase + chunkPos;
+        if (id >= a.numTiles) return -1;
+        ++chunkPos;
+        return id;
+    };
+    auto draw_step = [&]() {
+        if (needDraw && !haveNext) draw();
+    };
+    // (the compiler does not see that the stream state is the same in every lane: say so)
+    auto next_tile_s = [&]() {
+        const int id = sgpr(next_tile());
+        chunkBase = sgpr(chunkBase);
+        chunkPos = sgpr(chunkPos);
+        nextBase = sgpr(nextBase);
+        return id;
+    };
+    auto finish = [&]() {
+        __threadfence();
+        if (tt == 0 && atomicInc(a.work + 1, (unsigned)numTeams - 1u) == (unsigned)numTeams - 1u) {
+            __hip_atomic_store(a.work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (chunkBase >= a.numTiles) {
+        finish();
         STAMP_FLUSH;
         return;
     }
-    const TileDesc *tab = a.tiles + t0;
-    LeanTile cur = lean_desc(tab, 0, true);
-    LeanTile nx = lean_desc(tab, 1, count > 1);
-    LeanTile nn = lean_desc(tab, 2, count > 2);
+    const TileDesc *tab = a.tiles;
+    int id = next_tile_s();
+    LeanTile cur = lean_desc(tab, id, true);
+    id = next_tile_s();
+    LeanTile nx = lean_desc(tab, id < 0 ? 0 : id, id >= 0);
+    id = next_tile_s();
+    LeanTile nn = lean_desc(tab, id < 0 ? 0 : id, id >= 0);
 
     u4u pf[PFN];
 #pragma unroll
@@ -217,19 +283,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
             if (a.fbankFlag && (melFlags & 2) && melCh >= 0) {
 #pragma unroll
                 for (int r = 0; r < GT; ++r)
-                    if (r < dCount) ob[r * a.step + melCh] = dlv[r];
+                    if (slot_of(r) < dCount) ob[slot_of(r) * a.step + melCh] = dlv[r];
             }
             if (a.energyFlag && l == 0 && grp < dCount) ob[grp * a.step + JW] = dte; // main.c:243
             dCount = 0;
         }
     };
 
-    for (int ti = 0;; ++ti) {
-        const LeanTile d3 = lean_desc(tab, ti + 3, ti + 3 < count);
+    for (;;) {
+        const int id3 = next_tile_s();
+        const LeanTile d3 = lean_desc(tab, id3 < 0 ? 0 : id3, id3 >= 0);
         const int nf = cur.nf();
         {
             STAMP(0);
-            T *Zt = zbuf + grp * a.zPitch;
+            T *Zt = zbuf + slot_of(grp) * a.zPitch;
             cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
 
             // ---- sample pairs (2n, 2n+1), n = l + 16 r, times the window (Ham main.c:229); frame
@@ -239,9 +306,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
                 const cpx<T> *xp = reinterpret_cast<const cpx<T> *>(rows + (grp < nf ? grp : 0) * a.inc + 2 * l);
                 cpx<T> xs[NZ], ws[NZ];
                 lds_read_strided<NZ, 128>(xs, xp);
-                lds_read_strided<NZ, 128>(ws, winp);
+                if constexpr (!TREG) lds_read_strided<NZ, 128>(ws, winp);
 #pragma unroll
-                for (int r = 0; r < NZ; ++r) v[r] = xs[r] * ws[r];
+                for (int r = 0; r < NZ; ++r) v[r] = xs[r] * (TREG ? wreg[r] : ws[r]);
 #pragma unroll
                 for (int r = NZ; r < PPL; ++r) v[r] = cpx<T>{0.0f, 0.0f};
             }
@@ -258,6 +325,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
             if (nx.nf() > 0) {
                 team_sync<TEAM>();
                 expand(nx);
+                draw_step();
                 if (nn.nf() > 0) fetch(nn);
             }
             flush();
@@ -307,14 +375,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     av[c][t] = melA[8 * g + t];
-                    bw[c][t] = melB[(8 * g + t) * 64];
+                    if constexpr (!TREG) bw[c][t] = melB[(8 * g + t) * 64];
                 }
             };
-            auto mel_mac = [&](int c) {
+            auto mel_mac = [&](int c, int g) {
 #pragma unroll
                 for (int t = 0; t < 8; t += 2) {
-                    macc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c][t], bw[c][t], macc, 0, 0, 0);
-                    macc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c][t + 1], bw[c][t + 1], macc2, 0, 0, 0);
+                    macc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c][t], TREG ? mwreg[8 * g + t] : bw[c][t], macc, 0, 0, 0);
+                    macc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c][t + 1], TREG ? mwreg[8 * g + t + 1] : bw[c][t + 1], macc2, 0, 0, 0);
                 }
             };
             mel_load(0, 0);
@@ -322,7 +390,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
             for (int g = 0; g < MSG; ++g) {
                 if (g + 1 < MSG) mel_load((g + 1) & 1, g + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                mel_mac(g & 1);
+                mel_mac(g & 1, g);
             }
             macc += macc2;
             STAMP(5);
@@ -345,7 +413,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
                 for (int r = 0; r < GT; ++r) {
                     const T lv = tlog<T>(fmaxf(macc[r], 1.0f));
                     dlv[r] = lv;
-                    if (!a.fbankFlag && r < nf) fbk[r * a.P + melCh] = lv;
+                    if (!a.fbankFlag && slot_of(r) < nf) fbk[slot_of(r) * a.P + melCh] = lv;
                 }
             }
             if (a.energyFlag) dte = tlog<T>(te);
@@ -380,12 +448,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
             }
             team_sync<TEAM>();
         }
-        if (ti + 1 >= count) break;
+        if (nx.nf() == 0) break;
         cur = nx;
         nx = nn;
         nn = d3;
     }
     flush();
+    finish();
     STAMP_FLUSH;
 }
 

@@ -55,7 +55,9 @@ struct FrontArgs {
     T *out;
     int numTiles;
     int numUtts;              // entries of utts (k_lean256 walks them)
-    int tilesPerTeam;         // k_lean256: consecutive tiles every wave takes
+    int tilesPerTeam;         // k_lean256: tiles per chunk of a wave's work
+    unsigned *work;           // k_lean256: {chunks drawn, waves finished}, both zero at launch (the kernel
+                              // leaves them zero)
     long long planEnd;        // k_lean256: one past the last PCM byte the plan owns
     int wlen, inc, framesPerTile;
     int V, channels, bps;

@@ -14,7 +14,7 @@
 // chosen sites read the clock (and drain the LDS queue to do so), so the rest of the kernel runs
 // as in the shipped build.  stamps[0] = summed interval cycles, stamps[1] = intervals,
 // stamps[2] = summed wave lifetimes.
-#define STAMP_DECL unsigned long long st_last = 0, st_acc = 0, st_t0 = 0; unsigned st_n = 0; bool st_on = false;
+#define STAMP_DECL unsigned long long st_last = 0, st_acc = 0, st_t0 = 0, st_r0 = 0; unsigned st_n = 0; bool st_on = false;
 #define STAMP_READ(var)                                         \
     do {                                                        \
         __builtin_amdgcn_sched_barrier(0);                      \
@@ -25,6 +25,7 @@
 #define STAMP_START                                             \
     do {                                                        \
         STAMP_READ(st_t0);                                      \
+        st_r0 = __builtin_amdgcn_s_memrealtime(); \
         if ((a.stampBegin >> 15) & 1) { st_last = st_t0; st_on = true; } \
     } while (0)
 #define STAMP(i)                                                \
@@ -49,6 +50,11 @@
             atomicAdd(a.stamps + 0, st_acc);                                               \
             atomicAdd(a.stamps + 1, (unsigned long long)st_n);                             \
             atomicAdd(a.stamps + 2, t_ - st_t0);                                           \
+            const unsigned long long r1_ = __builtin_amdgcn_s_memrealtime();               \
+            atomicMin(a.stamps + 3, st_r0);                                                \
+            atomicMax(a.stamps + 4, r1_);                                                  \
+            atomicAdd(a.stamps + 5, r1_ - st_r0);                                          \
+            atomicAdd(a.stamps + 6, 1ull);                                                 \
         }                                                                                  \
     } while (0)
 #define SKIP(b) ((a.skip >> (b)) & 1) // ablation: results are wrong, only counters / time matter

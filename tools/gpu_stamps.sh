@@ -8,5 +8,5 @@ if [ $# -eq 0 ]; then set -- "0x8200 0" "0x1 1" "0x82 2" "0x4 3" "0x8 4" "0x10 5
 for iv in "$@"; do
   set -- $iv
   export MFCC_STAMP_BEGIN=$1 MFCC_STAMP_END=$2
-  timeout -k 10 120 python3 bench.py --workload $w --steps 2 --warmup 1 --no-cpu --no-host 2>&1 | grep "mfcc stamps" | tail -1
+  timeout -k 10 120 python3 bench.py --workload $w --steps 2 --warmup 1 --no-cpu --no-host 2>&1 | grep "mfcc stamps: interval" | tail -1
 done
