@@ -219,6 +219,18 @@ int MFCCShardNormalize(MFCCContext *ctx, MFCCPlan *plan, void *outDev, const dou
 int MFCCChannelSums(MFCCContext *ctx, const void *pcmDev, int channels, int bytesPerSample,
                     int64_t sampleBegin, int64_t count, int64_t *sums2Dev, void *stream);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the column sums of
+ * MFCCShardColumnSums -- sum x, sum x^2 per column, then the row count, 2*step+1 doubles to
+ * sumsDev, bit-identical to it -- of a [rows x step] matrix of float (MFCC_PREC_F32) or double in
+ * device memory, on the current device, without a context or a plan and without any hipMalloc /
+ * hipFree.  The per-chunk partial sums go to a 4 MiB device array inside the library (one copy
+ * per GPU, held until the process ends): ceil(rows / 256) * 2 * step * 8 bytes must fit, larger
+ * matrices are refused with MFCC_E_ARG.  All calls on one GPU share that array: calls that
+ * overlap there (two streams or threads) race; calls on one stream are ordered. */
+int MFCCColumnSumsNoAlloc(int precision, const void *dataDev, int64_t rows, int step, double *sumsDev,
+                          void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * The reference's lower-level API (mfcc.h:29-74), batched on the device: numFrames vectors back
  * to back in device memory, 0-based (the reference's 1-based Vector element [i] is element

@@ -68,7 +68,7 @@ EXPORTS = [
     "MFCCContextPassbandText", "MFCCContextTables", "MFCCPlanCreate", "MFCCPlanCreateShard",
     "MFCCPlanDestroy", "MFCCShardGeometry", "MFCCPlanTotalRows", "MFCCPlanRowOffset", "MFCCPlanNumFrames",
     "MFCCPlanSampleBegin", "MFCCPlanSampleCount", "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows",
-    "MFCCExtractDevice", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
+    "MFCCExtractDevice", "MFCCColumnSumsNoAlloc", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
     "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm", "MFCCFormatValue",
     "MFCCFFTDevice", "MFCCRealftDevice", "MFCCWave2FBankDevice", "MFCCFBank2MFCCDevice", "MFCCMel",
     "MFCCFBankTables", "MFCCWave2FBankTablesDevice", "MFCCFBank2MFCCDirectDevice",
@@ -130,6 +130,7 @@ def lib():
         getattr(L, name).restype = C.c_int64
     L.MFCCExtractDevice.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.MFCCShardColumnSums.argtypes = [vp, vp, vp, vp, vp]
+    L.MFCCColumnSumsNoAlloc.argtypes = [C.c_int, vp, C.c_int64, C.c_int, vp, vp]
     L.MFCCShardNormalize.argtypes = [vp, vp, vp, vp, vp]
     L.MFCCChannelSums.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp]
     L.MFCCPlanEnableTiming.argtypes = [vp, C.c_int]

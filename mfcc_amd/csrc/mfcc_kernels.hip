@@ -899,7 +899,7 @@ __global__ __launch_bounds__(kBlock) void k_colstats(const StatArgs<T> a)
 {
     __shared__ double sh[2 * kBlock];
     const int chunk = blockIdx.x;
-    const int u = a.chunkUtt[chunk];
+    const int u = a.chunkUtt ? a.chunkUtt[chunk] : 0; // no table: one utterance owns every chunk
     const UttDesc ud = a.utts[u];
     const int r0 = (chunk - ud.statBegin) * kStatRows;
     const int nr = min(kStatRows, ud.ownCount - r0);

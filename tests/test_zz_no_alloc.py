@@ -1,0 +1,77 @@
+"""GPU test of MFCCColumnSumsNoAlloc, the entry point for callers that cannot allocate device
+memory: through the C ABI, against MFCCShardColumnSums (the entry point it is a variant of) on the
+same matrix, bit for bit, on two calls in a row, the second with a smaller input; plus the refusal
+of matrices whose partial sums do not fit the fixed scratch array."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mfcc_amd as ma
+from mfcc_amd.presets import CONFIGS
+
+pytestmark = pytest.mark.gpu
+
+
+def _sums_with_plan(ctx, ch, bps, dev_pcm, n):
+    """The existing entry point: a shard plan that owns every frame of the recording."""
+    plan = ma.Plan(ctx, ch, bps, shard=(n, 0, ma.num_frames(n, ctx.cfg.wlen, ctx.cfg.inc), None))
+    out = plan.extract(dev_pcm)
+    sums = plan.shard_column_sums(out)
+    return out, sums
+
+
+def _sums_no_alloc(out, step, prec):
+    import torch
+    got = torch.full((2 * step + 1,), float("nan"), dtype=torch.float64, device=out.device)
+    stream = torch.cuda.current_stream(out.device).cuda_stream
+    ma._check(ma.lib().MFCCColumnSumsNoAlloc(prec, C.c_void_p(out.data_ptr()), out.shape[0], step,
+                                              C.c_void_p(got.data_ptr()), C.c_void_p(stream)))
+    return got
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_no_alloc_column_sums_match_the_plan_entry_point(precision):
+    import torch
+    kw = dict(CONFIGS["c5"])
+    prec = ma.PREC_F64 if precision == "f64" else ma.PREC_F32
+    cfg = ma.make_config(precision=prec, **kw)
+    ctx = ma.Context(cfg, 0)
+    ch, bps = 2, 3
+    # two calls in a row, the second with a smaller input (fewer rows, fewer chunks)
+    for n in (44100 * 7 + 311, 44100 * 2 + 17):
+        pcm = ma.synth_pcm(n, ch, bps, seed=0x5EED0000 + n, sample_rate=44100, tone_hz=440)
+        dev = torch.from_numpy(pcm).cuda()
+        out, want = _sums_with_plan(ctx, ch, bps, dev, n)
+        got = _sums_no_alloc(out, ctx.step, prec)
+        torch.cuda.synchronize()
+        w, g = want.cpu().numpy(), got.cpu().numpy()
+        assert g[-1] == out.shape[0] == w[-1]
+        assert np.array_equal(g.view(np.uint64), w.view(np.uint64))  # bit for bit (NaN columns included)
+
+
+def test_no_alloc_column_sums_edges():
+    import torch
+    step = 40
+    sums = torch.full((2 * step + 1,), 7.0, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    L = ma.lib()
+    # no rows: zeros, count 0
+    assert L.MFCCColumnSumsNoAlloc(ma.PREC_F32, None, 0, step, C.c_void_p(sums.data_ptr()), C.c_void_p(stream)) == 0
+    torch.cuda.synchronize()
+    assert float(sums.abs().sum()) == 0.0
+    # a small matrix against numpy (double accumulation of exactly representable values)
+    x = torch.arange(300 * step, dtype=torch.float32, device="cuda").reshape(300, step) % 97
+    assert L.MFCCColumnSumsNoAlloc(ma.PREC_F32, C.c_void_p(x.data_ptr()), 300, step, C.c_void_p(sums.data_ptr()),
+                                   C.c_void_p(stream)) == 0
+    torch.cuda.synchronize()
+    xn = x.cpu().numpy().astype(np.float64)
+    assert np.array_equal(sums[:step].cpu().numpy(), xn.sum(axis=0))
+    assert np.array_equal(sums[step:2 * step].cpu().numpy(), (xn * xn).sum(axis=0))
+    assert float(sums[-1]) == 300.0
+    # beyond the fixed scratch (4 MiB of partial sums): refused, with a message
+    rows = 256 * (4 * 1024 * 1024 // (2 * step * 8) + 1)
+    rc = L.MFCCColumnSumsNoAlloc(ma.PREC_F32, C.c_void_p(x.data_ptr()), rows, step, C.c_void_p(sums.data_ptr()),
+                                 C.c_void_p(stream))
+    assert rc == ma.E_ARG
+    assert b"scratch" in L.MFCCLastError()
