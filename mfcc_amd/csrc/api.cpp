@@ -1417,16 +1417,18 @@ extern "C" void MFCCFree(void *p) { free(p); }
 
 namespace {
 
-// Contexts are reused across MFCCWapper calls with the same numeric options.
+// Contexts are reused across MFCCWapper calls with the same numeric options.  A context is
+// immutable once created (host tables + device tables), so any number of threads may run plans on
+// it at once (the reference's thread-per-file model, README.md:19,134).  A caller holds a shared
+// reference for the length of its call: an entry pushed out of the cache is only destroyed when
+// its last user lets go.
+typedef std::shared_ptr<MFCCContext> CtxRef;
 struct CtxCache {
     std::mutex mu;
-    std::vector<std::pair<std::string, MFCCContext *>> items;
-    ~CtxCache()
-    {
-        for (auto &it : items) MFCCContextDestroy(it.second);
-    }
+    std::vector<std::pair<std::string, CtxRef>> items;
 };
 CtxCache g_cache;
+constexpr size_t kCtxCacheSize = 8;
 
 std::string cfg_key(const MFCCConfig &c, int device)
 {
@@ -1439,7 +1441,7 @@ std::string cfg_key(const MFCCConfig &c, int device)
     return s;
 }
 
-int cached_context(const MFCCConfig &cfgIn, MFCCContext **out)
+int cached_context(const MFCCConfig &cfgIn, CtxRef *out)
 {
     MFCCConfig cfg;
     memset(&cfg, 0, sizeof cfg); // zero the padding so the key is well defined
@@ -1464,12 +1466,9 @@ int cached_context(const MFCCConfig &cfgIn, MFCCContext **out)
     MFCCContext *c = nullptr;
     const int rc = MFCCContextCreate(&cfg, device, &c);
     if (rc) return rc;
-    if (g_cache.items.size() >= 8) {
-        MFCCContextDestroy(g_cache.items.front().second);
-        g_cache.items.erase(g_cache.items.begin());
-    }
-    g_cache.items.emplace_back(key, c);
-    *out = c;
+    if (g_cache.items.size() >= kCtxCacheSize) g_cache.items.erase(g_cache.items.begin()); // oldest out
+    g_cache.items.emplace_back(key, CtxRef(c, MFCCContextDestroy));
+    *out = g_cache.items.back().second;
     return MFCC_OK;
 }
 
@@ -1528,8 +1527,9 @@ extern "C" int MFCCWapperMem(const MFCCConfig *cfg, const void *wavFile, size_t 
     if (cfg->sampleRate != w.sampleRate) /* main.c:192-196 */
         return set_error("Sample rate not right (config %d, file %d)", cfg->sampleRate, w.sampleRate),
                MFCC_E_SAMPLE_RATE;
-    MFCCContext *c = nullptr;
-    if ((rc = cached_context(*cfg, &c))) return rc;
+    CtxRef cref;
+    if ((rc = cached_context(*cfg, &cref))) return rc;
+    MFCCContext *c = cref.get();
     if (step) *step = c->step;
     std::vector<int64_t> off(1, 0), ns(1, w.numSamples), rowOff, frames;
     std::vector<double> rows;
@@ -1713,8 +1713,9 @@ extern "C" int MFCCWapperList(const char *iniPath)
     const bool quiet = getenv("MFCC_QUIET") != nullptr;
     const bool timing = getenv("MFCC_LIST_TIMING") != nullptr;
     if (!quiet) printf("finish reading the config.ini\n"); /* main.c:140 */
-    MFCCContext *c = nullptr;
-    if ((rc = cached_context(cfg, &c))) return rc;
+    CtxRef cref; // held until the list is done
+    if ((rc = cached_context(cfg, &cref))) return rc;
+    MFCCContext *c = cref.get();
     if (!quiet) {
         char text[256];
         MFCCContextPassbandText(c, text, sizeof text);

@@ -669,3 +669,38 @@ def test_whole_utterance_finish_variants(oracle, name, frames, force_sweeps, mon
     for p, g in zip(pcms, got):
         if g.shape[0] >= 5:
             _compare(g, oracle.extract_pcm_bytes(ocfg, p, ch, bps), kw, False)
+
+
+def test_wapper_from_many_threads_with_more_configs_than_cache_slots():
+    """The reference's model is a thread per file (README.md:19,134): 8 threads call MFCCWapperMem
+    with 12 different option sets (the context cache holds 8, so entries are pushed out while
+    other threads still run on them); every result must equal the single-threaded one bit for bit."""
+    import threading
+    variants = []
+    for i in range(12):
+        kw = dict(CONFIGS["c3" if i % 2 else "c2"])
+        kw["bankNum"] = 24 + i  # 12 distinct table sets
+        variants.append(kw)
+    pcm = _pcm(16000 * 2 + 37, 1, 2, 77, 16000)
+    wav = ma.wav_bytes(pcm, 1, 2, 16000)
+    cfgs = [ma.make_config(**kw) for kw in variants]
+    want = [ma.wapper_mem(cfg, wav) for cfg in cfgs]
+    errors = []
+
+    def work(t):
+        try:
+            for rep in range(3):
+                for j in range(len(cfgs)):
+                    i = (j * 5 + t + rep) % len(cfgs)
+                    got = ma.wapper_mem(cfgs[i], wav)
+                    if not np.array_equal(got.view(np.uint64), want[i].view(np.uint64)):
+                        errors.append("thread %d config %d differs" % (t, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (t, e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
