@@ -139,7 +139,7 @@ extern "C" int MFCCConfigDefaults(MFCCConfig *cfg)
     cfg->delwin = 2;
     cfg->saveType = MFCC_SAVE_E;
     cfg->numThreads = 1;
-    cfg->precision = MFCC_PREC_F32;
+    cfg->precision = MFCC_PREC_F64; // the reference computes in double; single precision is the opt-in fast mode
     return MFCC_OK;
 }
 

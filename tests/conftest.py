@@ -18,3 +18,14 @@ def oracle():
     binding.build()
     binding.lib()
     return binding
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Largest achieved error per column kind over the GPU-vs-oracle comparisons of this run."""
+    import util
+    if not util.ACHIEVED:
+        return
+    terminalreporter.write_line("achieved maximum errors (error / tolerance of the comparison it came from):")
+    for kind in sorted(util.ACHIEVED):
+        err, tol = util.ACHIEVED[kind]
+        terminalreporter.write_line("  %-16s %.3g / %.3g" % (kind, err, tol))

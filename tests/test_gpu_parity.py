@@ -184,7 +184,7 @@ def test_ragged_batch_and_edge_lengths(oracle, finish, monkeypatch):
     kw = CONFIGS["c3"]
     lens = [0, 1, 399, 400, 559, 560, 561, 5000, 16000, 401, 33333] + ([400 + 160 * 2500] if finish == "too long" else [])
     pcms = [_pcm(n, 1, 2, 100 + i, 16000) for i, n in enumerate(lens)]
-    cfg = ma.make_config(**kw)
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
     got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 1, 2)
     ocfg = oracle.make_config(**kw)
     for n, p, g in zip(lens, pcms, got):
@@ -208,7 +208,7 @@ def test_pcm_layouts_and_misaligned_offsets(oracle, ch, bps, shift):
         pcm = _pcm(n, ch, bps, 40 + shift, 16000)
     ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, ch, bps)
     import torch
-    cfg = ma.make_config(**kw)
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
     ctx = ma.Context(cfg, 0)
     buf = np.zeros(pcm.size + 64, dtype=np.uint8)
     buf[shift:shift + pcm.size] = pcm
@@ -235,7 +235,7 @@ def test_fft_length_debug_columns(oracle):
     kw = dict(CONFIGS["c2"], fftLength=7, brightFlag=1, subBandEFlag=3)
     pcm = _pcm(4000, 1, 2, 12, 16000)
     ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
-    got = run_product_batch(ma, ma.make_config(**kw), [pcm.tobytes()], 1, 2)[0]
+    got = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], 1, 2)[0]
     _compare(got, ref, kw, False)
 
 
@@ -245,7 +245,7 @@ def test_silence_matches_reference_semantics(oracle):
     kw = dict(CONFIGS["c1a"])
     pcm = np.zeros(20000 * 2 * 3, dtype=np.uint8)
     ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 2, 3)
-    got = run_product_batch(ma, ma.make_config(**kw), [pcm.tobytes()], 2, 3)[0]
+    got = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], 2, 3)[0]
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     assert np.array_equal(np.isneginf(got), np.isneginf(ref))
     fin = np.isfinite(ref)
@@ -263,7 +263,7 @@ def test_zcr_is_exact_on_near_cancelling_samples(oracle):
     x[1::2] = (x[0::2].astype(np.int64) * 97) // 100  # x[i] = 0.97 x[i-1] exactly in integers
     pcm = x.view(np.uint8)
     ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
-    got = run_product_batch(ma, ma.make_config(**kw), [pcm.tobytes()], 1, 2)[0]
+    got = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], 1, 2)[0]
     assert np.array_equal(got[:, 40], ref[:, 40].astype(np.float32).astype(np.float64))
 
 
@@ -274,7 +274,7 @@ def test_wapper_entry_points_and_writers(oracle, tmp_path):
     wav = tmp_path / "a.wav"
     wav.write_bytes(ma.wav_bytes(pcm, 1, 2, 16000, extra_chunk=(b"LIST", b"info")))
     ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
-    cfg = ma.make_config(saveType=ma.SAVE_N, **kw)
+    cfg = ma.make_config(precision=ma.PREC_F32, saveType=ma.SAVE_N, **kw)
     out = tmp_path / "a.npy"
     feat = ma.wapper(cfg, str(wav), str(out))
     _compare(feat, ref, kw, False)
@@ -282,10 +282,10 @@ def test_wapper_entry_points_and_writers(oracle, tmp_path):
     feat2 = ma.wapper_mem(cfg, wav.read_bytes())
     assert np.array_equal(feat, feat2)
     with pytest.raises(ma.MFCCError) as e:
-        ma.wapper(ma.make_config(**dict(kw, sampleRate=8000)), str(wav))
+        ma.wapper(ma.make_config(precision=ma.PREC_F32, **dict(kw, sampleRate=8000)), str(wav))
     assert e.value.code == ma.E_SAMPLE_RATE
     with pytest.raises(ma.MFCCError) as e:
-        ma.wapper(ma.make_config(**dict(kw, vecNum=2)), str(wav))
+        ma.wapper(ma.make_config(precision=ma.PREC_F32, **dict(kw, vecNum=2)), str(wav))
     assert e.value.code == ma.E_VECNUM
     # whole-run entry point with a list of three files, one of them unreadable
     pcm2 = _pcm(5000, 1, 2, 22, 16000)
@@ -317,7 +317,7 @@ def test_wapper_list_batches_mixed_layouts(oracle, tmp_path):
     closes a batch and carries the files already read over to the next one), with a missing file
     and a file shorter than one frame in between: every output equals the per-file entry point's."""
     kw = dict(CONFIGS["c3"], vecNum=1)
-    cfg = ma.make_config(saveType=ma.SAVE_B, **kw)
+    cfg = ma.make_config(saveType=ma.SAVE_B, **kw)  # (the ini below names no precision: the default)
     layouts = [(1, 2), (1, 2), (2, 3), (1, 2), (2, 2), (2, 2), (1, 3), (1, 2)]
     lines, expect = [], {}
     for i in range(40):
@@ -367,7 +367,7 @@ def test_frame_sharded_recording_matches_whole(oracle, name, n, ch, bps):
     kw = dict(CONFIGS[name], zeroMeanSigFlag=1)
     pcm = _pcm(n, ch, bps, 31, kw["sampleRate"])
     ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, ch, bps)
-    cfg = ma.make_config(**kw)
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
     ctx = ma.Context(cfg, 0)
     dev = torch.from_numpy(pcm).cuda()
     total = ma.num_frames(n, kw["wlen"], kw["inc"])
@@ -410,7 +410,7 @@ def test_batch_order_and_shift_invariance_at_full_size():
     kw = dict(CONFIGS["c2"], preemphasise=0.0)
     n, U = 160000, 64
     pcms = [_pcm(n, 1, 2, 500 + u, 16000, tone=0) for u in range(U)]
-    cfg = ma.make_config(**kw)
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
     a = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 1, 2)
     perm = np.random.default_rng(1).permutation(U)
     b = run_product_batch(ma, cfg, [pcms[i].tobytes() for i in perm], 1, 2)
@@ -427,7 +427,7 @@ def test_linearity_of_the_power_path_at_full_size():
     kw = dict(CONFIGS["c2"], energyFlag=1)
     n = 160000
     x = np.frombuffer(_pcm(n, 1, 2, 900, 16000, tone=0).tobytes(), dtype=np.int16) // 4
-    cfg = ma.make_config(**kw)
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
     a = run_product_batch(ma, cfg, [x.astype(np.int16).tobytes()], 1, 2)[0]
     b = run_product_batch(ma, cfg, [(x * 2).astype(np.int16).tobytes()], 1, 2)[0]
     assert np.all(a[:, :40] > 1.0)
@@ -438,7 +438,7 @@ def test_kernel_timing_api():
     import torch
     kw = CONFIGS["c2"]
     pcm = _pcm(160000, 1, 2, 1, 16000)
-    ctx = ma.Context(ma.make_config(**kw), 0)
+    ctx = ma.Context(ma.make_config(precision=ma.PREC_F32, **kw), 0)
     plan = ma.Plan(ctx, 1, 2, [0], [160000])
     assert plan.last_kernel_ms() < 0
     plan.enable_timing(True)
@@ -560,7 +560,7 @@ def test_file_sharded_whole_run(tmp_path):
     equal to the per-file entry point's."""
     from mfcc_amd import sharding
     kw = dict(CONFIGS["c2"])
-    cfg = ma.make_config(saveType=ma.SAVE_B, **kw)
+    cfg = ma.make_config(saveType=ma.SAVE_B, **kw)  # (the ini below names no precision: the default)
     lines, pcms = [], []
     for i in range(9):
         pcm = _pcm(2000 + 900 * i, 1, 2, 300 + i, 16000)
@@ -663,7 +663,7 @@ def test_whole_utterance_finish_variants(oracle, name, frames, force_sweeps, mon
     ch, bps = _layout(kw)
     lens = [kw["wlen"] + (frames - 1) * kw["inc"] + 3, kw["wlen"], kw["wlen"] - 1, kw["wlen"] + 7 * kw["inc"]]
     pcms = [_pcm(n, ch, bps, 500 + i, kw["sampleRate"]) for i, n in enumerate(lens)]
-    got = run_product_batch(ma, ma.make_config(**kw), [p.tobytes() for p in pcms], ch, bps)
+    got = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [p.tobytes() for p in pcms], ch, bps)
     ocfg = oracle.make_config(**kw)
     assert got[0].shape[0] == frames and got[2].shape[0] == 0
     for p, g in zip(pcms, got):
@@ -683,7 +683,7 @@ def test_wapper_from_many_threads_with_more_configs_than_cache_slots():
         variants.append(kw)
     pcm = _pcm(16000 * 2 + 37, 1, 2, 77, 16000)
     wav = ma.wav_bytes(pcm, 1, 2, 16000)
-    cfgs = [ma.make_config(**kw) for kw in variants]
+    cfgs = [ma.make_config(precision=ma.PREC_F32, **kw) for kw in variants]
     want = [ma.wapper_mem(cfg, wav) for cfg in cfgs]
     errors = []
 
@@ -704,3 +704,52 @@ def test_wapper_from_many_threads_with_more_configs_than_cache_slots():
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+def _tonal_pcm(n, ch, bps, sr, seed):
+    """A near-full-scale 1 kHz tone plus noise 90 dB below full scale: the input with the widest
+    per-frame dynamic range the PCM format allows (weak channels sit at the noise floor)."""
+    rng = np.random.default_rng(seed)
+    fs = float(2 ** (8 * bps - 1) - 1)
+    t = np.arange(n) / sr
+    cols = []
+    for c in range(ch):
+        x = 0.98 * fs * np.sin(2 * np.pi * (1000.0 + 37.0 * c) * t + 0.3 * c) + rng.normal(0.0, fs * 10 ** (-90 / 20), n)
+        cols.append(np.clip(np.rint(x), -fs - 1, fs).astype(np.int64))
+    inter = np.stack(cols, axis=1).reshape(-1)
+    raw = np.zeros((inter.size, bps), dtype=np.uint8)
+    for b in range(bps):
+        raw[:, b] = (inter >> (8 * b)) & 0xFF
+    return raw.reshape(-1)
+
+
+@pytest.mark.parametrize("name", ["c2", "c1a"])
+def test_tonal_input_error_envelope(oracle, name):
+    """Where single precision stops meeting the 1e-4 log-mel tolerance.  The rounding noise of a
+    single-precision FFT is relative to the frame's energy, so a channel far below the strongest one
+    of its frame carries a larger relative error.  Measured here on the worst input the format
+    allows; asserted: double precision (the library's default) meets the tolerance everywhere,
+    single precision meets it for every channel within 60 dB (13.8 log units) of the frame's
+    strongest channel, and its error stays below 5e-3 at any level.  The envelope is printed."""
+    kw = dict(CONFIGS[name], regreOrder=1, energyFlag=0, zeroCrossingFlag=0, brightFlag=0, subBandEFlag=0)
+    ch, bps = _layout(kw)
+    sr = kw["sampleRate"]
+    pcm = _tonal_pcm(sr // 2, ch, bps, sr, 11)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, ch, bps)
+    P, V = kw["bankNum"], kw["vecNum"]
+    assert ref.shape[1] == P * V
+    got64 = run_product_batch(ma, ma.make_config(**kw), [pcm.tobytes()], ch, bps)[0]  # default precision
+    assert ma.make_config(**kw).precision == ma.PREC_F64
+    assert np.max(np.abs(got64 - ref)) < 1e-9
+    got32 = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], ch, bps)[0]
+    err = np.abs(got32 - ref).reshape(-1, V, P)
+    lev = ref.reshape(-1, V, P)
+    below = np.max(lev, axis=2, keepdims=True) - lev  # log units below the frame's strongest channel
+    edges = [0, 4.6, 9.2, 13.8, 18.4, 23.0, 27.6, 1e9]  # 0, 20, 40, ... dB
+    print("\n%s: single-precision log-mel error by level below the frame's strongest channel" % name)
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        m = (below >= lo) & (below < hi)
+        if m.any():
+            print("  %5.0f .. %5.0f dB: %7d values, max error %.3g" % (lo * 4.343, min(hi, 40) * 4.343, int(m.sum()), float(err[m].max())))
+    assert float(err[below < 13.8].max()) <= 1e-4
+    assert float(err.max()) <= 5e-3

@@ -47,7 +47,7 @@ def _free_port():
 def _oracle_shard(ob, kw, pcm_all, ch, bps, total, fb, fe):
     """What one rank computes: static + delta features of its extended frame range from the
     instants the plan names, with the pre-emphasis predecessor supplied by the lead instant."""
-    cfg = ma.make_config(**kw)
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
     g = ma.shard_geometry(cfg, total, fb, fe)
     bpi = ch * bps
     raw = pcm_all[g["sample_begin"] * bpi:(g["sample_begin"] + g["sample_count"]) * bpi]

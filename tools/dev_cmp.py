@@ -23,7 +23,7 @@ ch, bps = tp._layout(kw)
 n = kw["sampleRate"] + 123
 pcm = tp._pcm(n, ch, bps, 7, kw["sampleRate"])
 ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, ch, bps)
-got = run_product_batch(ma, ma.make_config(**kw), [pcm.tobytes()], ch, bps)[0]
+got = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], ch, bps)[0]
 kinds = column_kinds(kw) * kw.get("vecNum", 1)
 print("shape", got.shape, "nan got/ref", int(np.isnan(got).sum()), int(np.isnan(ref).sum()))
 bad = np.argwhere(np.isnan(got) != np.isnan(ref))

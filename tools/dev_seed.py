@@ -44,7 +44,7 @@ pcms = [tp._pcm(n, ch, bps, seed * 10 + i, sr, tone=0).tobytes() for i, n in enu
 print(kw, ch, bps)
 ocfg = oracle.make_config(**kw)
 refs = [oracle.extract_pcm_bytes(ocfg, np.frombuffer(p, dtype=np.uint8), ch, bps) for p in pcms]
-gots = run_product_batch(ma, ma.make_config(**kw), pcms, ch, bps, pad=int(rng.integers(0, 7)))
+gots = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), pcms, ch, bps, pad=int(rng.integers(0, 7)))
 kinds = np.array(column_kinds(kw) * kw["vecNum"])
 t = oracle.fbank_tables(wlen, sr, bank, -1, -1)
 for u, (g, r) in enumerate(zip(gots, refs)):

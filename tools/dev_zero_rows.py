@@ -15,7 +15,7 @@ from util import run_product_batch  # noqa: E402
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 kw = dict(CONFIGS["c2"], preemphasise=0.0)
 pcms = [ma.synth_pcm(160000, 1, 2, seed=0x5EED0000 + 500 + u, sample_rate=16000, tone_hz=0) for u in range(U)]
-a = run_product_batch(ma, ma.make_config(**kw), [p.tobytes() for p in pcms], 1, 2)
+a = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [p.tobytes() for p in pcms], 1, 2)
 allrows = np.concatenate(a)
 zero = np.nonzero(np.all(allrows == 0, axis=1))[0]
 print("rows", allrows.shape[0], "zero rows", len(zero))

@@ -36,7 +36,7 @@ def main():
     buf = np.zeros(stride * utts, dtype=np.uint8)
     for u in range(utts):
         buf[u * stride:u * stride + one.size] = one
-    ctx = ma.Context(ma.make_config(**kw), 0)
+    ctx = ma.Context(ma.make_config(precision=ma.PREC_F32, **kw), 0)
     plan = ma.Plan(ctx, ch, bps, np.arange(utts, dtype=np.int64) * stride, np.full(utts, n, dtype=np.int64))
     dev = torch.from_numpy(buf).cuda()
     out = plan.alloc_output()

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(
 import mfcc_amd as ma
 from mfcc_amd.presets import CONFIGS
 kw = CONFIGS["c3"]
-cfg = ma.make_config(**kw)
+cfg = ma.make_config(precision=ma.PREC_F32, **kw)
 pcm = ma.synth_pcm(160000, 1, 2, seed=3, sample_rate=16000, tone_hz=0)
 wav = ma.wav_bytes(pcm, 1, 2, 16000)
 ma.wapper_mem(cfg, wav)
