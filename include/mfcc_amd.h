@@ -286,6 +286,10 @@ float MFCCPlanLastKernelMs(MFCCPlan *plan);
  * channels * bytesPerSample starting at channel `ch`. */
 int MFCCSynthPcm(void *dst, int channels, int ch, int bytesPerSample, int64_t numSamples,
                  uint64_t seed, int sampleRate, int toneHz);
+/* The same stream from sample firstSample on (numSamples of them, written from dst on): ranges of
+ * one long recording can be synthesised independently. */
+int MFCCSynthPcmAt(void *dst, int channels, int ch, int bytesPerSample, int64_t firstSample,
+                   int64_t numSamples, uint64_t seed, int sampleRate, int toneHz);
 
 #ifdef __cplusplus
 }

@@ -69,7 +69,7 @@ EXPORTS = [
     "MFCCPlanDestroy", "MFCCShardGeometry", "MFCCPlanTotalRows", "MFCCPlanRowOffset", "MFCCPlanNumFrames",
     "MFCCPlanSampleBegin", "MFCCPlanSampleCount", "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows",
     "MFCCExtractDevice", "MFCCColumnSumsNoAlloc", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
-    "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm", "MFCCFormatValue",
+    "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm", "MFCCSynthPcmAt", "MFCCFormatValue",
     "MFCCFFTDevice", "MFCCRealftDevice", "MFCCWave2FBankDevice", "MFCCFBank2MFCCDevice", "MFCCMel",
     "MFCCFBankTables", "MFCCWave2FBankTablesDevice", "MFCCFBank2MFCCDirectDevice",
 ]
@@ -138,6 +138,7 @@ def lib():
     L.MFCCPlanLastKernelMs.restype = C.c_float
     L.MFCCSynthPcm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_int,
                                C.c_int]
+    L.MFCCSynthPcmAt.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int, C.c_int]
     L.MFCCFormatValue.argtypes = [C.c_double, C.c_int, C.c_char_p, C.c_size_t]
     L.MFCCFFTDevice.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]
     L.MFCCRealftDevice.argtypes = [C.c_int, vp, C.c_int, C.c_int, vp]

@@ -161,7 +161,16 @@ extern "C" int MFCCWriteFeatures(const char *path, const double *data, long numF
 extern "C" int MFCCSynthPcm(void *dst, int channels, int ch, int bytesPerSample, int64_t numSamples,
                             uint64_t seed, int sampleRate, int toneHz)
 {
-    if (!dst || channels < 1 || ch < 0 || ch >= channels || (bytesPerSample != 2 && bytesPerSample != 3))
+    return MFCCSynthPcmAt(dst, channels, ch, bytesPerSample, 0, numSamples, seed, sampleRate, toneHz);
+}
+
+// Samples firstSample .. firstSample + numSamples - 1 of the same stream, written from dst on: the
+// generator's state after firstSample steps is u0 a^k + c (a^k - 1) / (a - 1), found by doubling,
+// so ranges of one long stream can be made independently (by threads, or by the ranks of a job).
+extern "C" int MFCCSynthPcmAt(void *dst, int channels, int ch, int bytesPerSample, int64_t firstSample,
+                              int64_t numSamples, uint64_t seed, int sampleRate, int toneHz)
+{
+    if (!dst || channels < 1 || ch < 0 || ch >= channels || (bytesPerSample != 2 && bytesPerSample != 3) || firstSample < 0)
         return set_error("bad argument to MFCCSynthPcm"), MFCC_E_ARG;
     // One period of a sine in 1/1024 turns, amplitude 8192 (-12 dBFS of 16-bit), built with
     // integer arithmetic only: Bhaskara's approximation sin(x) ~ 16x(pi-x)/(5pi^2-4x(pi-x)).
@@ -179,8 +188,21 @@ extern "C" int MFCCSynthPcm(void *dst, int channels, int ch, int bytesPerSample,
     unsigned char *out = static_cast<unsigned char *>(dst);
     const size_t stride = (size_t)channels * bytesPerSample;
     uint64_t u = seed;
-    uint64_t phase = 0; // in 1/2^32 turns
+    {
+        // (mul, add) of k steps at once: composing a step with itself doubles k
+        uint64_t accMul = 1, accAdd = 0, curMul = 6364136223846793005ull, curAdd = 1442695040888963407ull;
+        for (uint64_t k = (uint64_t)firstSample; k; k >>= 1) {
+            if (k & 1) {
+                accMul *= curMul;
+                accAdd = accAdd * curMul + curAdd;
+            }
+            curAdd = (curMul + 1) * curAdd;
+            curMul *= curMul;
+        }
+        u = u * accMul + accAdd;
+    }
     const uint64_t dphase = toneHz > 0 ? (((uint64_t)toneHz << 32) / (uint64_t)sampleRate) : 0;
+    uint64_t phase = (dphase * (uint64_t)firstSample) & 0xFFFFFFFFull; // in 1/2^32 turns
     for (int64_t i = 0; i < numSamples; ++i) {
         u = u * 6364136223846793005ull + 1442695040888963407ull;
         int32_t v = (int32_t)((((u >> 40) & 0xFFFF) + ((u >> 20) & 0xFFFF)) >> 1) - 32768;

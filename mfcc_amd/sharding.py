@@ -40,12 +40,15 @@ def combine_sums(local, dist=None, group=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local.clone()
     import torch
-    parts = [torch.empty_like(local) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(parts, local.contiguous(), group=group)
+    src = local.contiguous()
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        src = src.cpu()  # gloo moves host memory (CPU tests, one-device rehearsals); RCCL takes device tensors
+    parts = [torch.empty_like(src) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, src, group=group)
     total = parts[0].clone()
     for p in parts[1:]:
         total += p
-    return total
+    return total.to(local.device)
 
 
 def extract_recording_shard(ma, ctx, pcm_shard_dev, channels, bytes_per_sample, total_samples,
