@@ -70,6 +70,8 @@ typedef struct MFCCConfig {
     int numThreads; /* host threads used by MFCCWapperList for file reading and writing */
     int precision;  /* MFCC_PREC_* */
     char fileList[MFCC_MAX_PATH];
+    int numDevices; /* GPUs MFCCWapperList spreads its batches over ([IO] numDevices): 0 = all visible;
+                       -k = k device threads round-robin over the visible GPUs (several streams per GPU) */
 } MFCCConfig;
 
 /* Thread-local message of the last failed call ("" if none). */
@@ -78,7 +80,7 @@ const char *MFCCLastError(void);
 /* Releases any buffer this library handed out (feature matrices). */
 void MFCCFree(void *p);
 
-/* Fills *cfg with neutral defaults (all flags 0, regreOrder 1, numThreads 1, f32). */
+/* Fills *cfg with neutral defaults (all flags 0, regreOrder 1, numThreads 1, all GPUs, f64). */
 int MFCCConfigDefaults(MFCCConfig *cfg);
 
 /*
@@ -218,6 +220,20 @@ int MFCCShardNormalize(MFCCContext *ctx, MFCCPlan *plan, void *outDev, const dou
  * written to sums2Dev.  Ranks add these up to feed MFCCPlanCreateShard's chanSum2. */
 int MFCCChannelSums(MFCCContext *ctx, const void *pcmDev, int channels, int bytesPerSample,
                     int64_t sampleBegin, int64_t count, int64_t *sums2Dev, void *stream);
+
+/*
+ * One very long recording over several GPUs, driven from this one process: the per-file body of
+ * main.c:198-266 (rows, pre-emphasis, frames, deltas, README's zero-mean and z-norm) with the frames
+ * split into numShards contiguous ranges, one host thread and one GPU per range (devices[g], or the
+ * visible GPUs in turn when devices is NULL; numShards 0 = one per visible GPU; shards may share a
+ * GPU).  Each range recomputes the halo frames its deltas need; the only exchange is of the integer
+ * channel sums and of the z-norm column sums (2*step+1 doubles), added by every shard in shard order.
+ * pcm: host pointer to the interleaved PCM payload (numSamples instants); features: host matrix
+ * [MFCCNumFrames x MFCCStep] of float (MFCC_PREC_F32) or double, filled in frame order.
+ */
+int MFCCExtractRecording(const MFCCConfig *cfg, const void *pcm, int channels, int bytesPerSample,
+                         int64_t numSamples, int numShards, const int *devices, void *features,
+                         int64_t *numFrames);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): the column sums of

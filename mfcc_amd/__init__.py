@@ -49,6 +49,7 @@ class MFCCConfig(C.Structure):
         ("numThreads", C.c_int),
         ("precision", C.c_int),
         ("fileList", C.c_char * MAX_PATH),
+        ("numDevices", C.c_int),
     ]
 
 
@@ -68,7 +69,7 @@ EXPORTS = [
     "MFCCContextPassbandText", "MFCCContextTables", "MFCCPlanCreate", "MFCCPlanCreateShard",
     "MFCCPlanDestroy", "MFCCShardGeometry", "MFCCPlanTotalRows", "MFCCPlanRowOffset", "MFCCPlanNumFrames",
     "MFCCPlanSampleBegin", "MFCCPlanSampleCount", "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows",
-    "MFCCExtractDevice", "MFCCColumnSumsNoAlloc", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
+    "MFCCExtractDevice", "MFCCExtractRecording", "MFCCColumnSumsNoAlloc", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
     "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm", "MFCCSynthPcmAt", "MFCCFormatValue",
     "MFCCFFTDevice", "MFCCRealftDevice", "MFCCWave2FBankDevice", "MFCCFBank2MFCCDevice", "MFCCMel",
     "MFCCFBankTables", "MFCCWave2FBankTablesDevice", "MFCCFBank2MFCCDirectDevice",
@@ -130,6 +131,7 @@ def lib():
         getattr(L, name).restype = C.c_int64
     L.MFCCExtractDevice.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.MFCCShardColumnSums.argtypes = [vp, vp, vp, vp, vp]
+    L.MFCCExtractRecording.argtypes = [cfgp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(C.c_int64)]
     L.MFCCColumnSumsNoAlloc.argtypes = [C.c_int, vp, C.c_int64, C.c_int, vp, vp]
     L.MFCCShardNormalize.argtypes = [vp, vp, vp, vp, vp]
     L.MFCCChannelSums.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp]
@@ -367,6 +369,23 @@ def wapper_mem(cfg, wav_file_bytes, out_path=None):
         return np.ctypeslib.as_array(feat, shape=(max(n, 1),))[:n].reshape(nf.value, st.value).copy()
     finally:
         lib().MFCCFree(feat)
+
+
+def extract_recording(cfg, pcm, channels, bytes_per_sample, num_shards=0, devices=None):
+    """MFCCExtractRecording: one long recording (interleaved PCM bytes on the host) over num_shards
+    frame ranges, one GPU and host thread each; returns the [numFrames, step] matrix."""
+    pcm = np.ascontiguousarray(np.frombuffer(bytes(pcm), dtype=np.uint8) if not isinstance(pcm, np.ndarray) else pcm)
+    n = pcm.size // (channels * bytes_per_sample)
+    T = num_frames(n, cfg.wlen, cfg.inc)
+    out = np.zeros((T, step(cfg)), dtype=np.float64 if cfg.precision == PREC_F64 else np.float32)
+    dev = None
+    if devices is not None:
+        dev = (C.c_int * len(devices))(*devices)
+    nf = C.c_int64()
+    _check(lib().MFCCExtractRecording(C.byref(cfg), pcm.ctypes.data, channels, bytes_per_sample, n, num_shards,
+                                      dev, out.ctypes.data, C.byref(nf)))
+    assert nf.value == T
+    return out
 
 
 def wapper_list(ini_path):

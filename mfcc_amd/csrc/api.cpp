@@ -11,6 +11,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <array>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -1744,38 +1745,61 @@ extern "C" int MFCCWapperList(const char *iniPath)
     const int nth = std::max(1, cfg.numThreads);
     const size_t el = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
     const size_t kBatchPcm = (size_t)64 << 20, kBatchOut = (size_t)256 << 20, kBatchFiles = 4096;
-    constexpr int kSlots = 3;
-    ListBatch slots[kSlots];
+    // One device thread per GPU ([IO] numDevices, default: every visible one): each takes the next
+    // loaded batch, so the files spread over the GPUs by themselves and nothing is exchanged
+    // (every file's result is independent of the device and of the batch it travels in).
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) visible = 1;
+    // numDevices < 0: that many device threads spread round-robin over the visible GPUs (several
+    // streams per GPU, whose copies and kernels overlap)
+    const int numDev = cfg.numDevices < 0 ? std::min(-cfg.numDevices, 64)
+                                          : std::max(1, std::min(cfg.numDevices > 0 ? cfg.numDevices : visible, visible));
+    const int kSlots = 2 * numDev + 1;
+    std::vector<ListBatch> slots((size_t)kSlots);
     BlockingQueue<ListBatch *> freeQ, loadedQ, computedQ;
     for (auto &sl : slots) freeQ.push(&sl);
     double tRead = 0, tPack = 0, tDev = 0, tWrite = 0;
+    std::mutex tMu;
 
-    std::thread devThread([&]() {
-        GrowDevBuf dPcm, dOut;
-        hipStream_t st = nullptr;
-        bool ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreate(&st) == hipSuccess;
-        for (;;) {
-            ListBatch *b = loadedQ.pop();
-            if (!b) break;
-            const double t0 = now_s();
-            if (!ok) {
-                set_error("no HIP device available (the library has no CPU path)");
-                b->rc = MFCC_E_DEVICE;
-            } else {
-                b->rc = list_device_stage(c, *b, dPcm, dOut, st);
+    std::vector<std::thread> devThreads;
+    for (int d = 0; d < numDev; ++d)
+        devThreads.emplace_back([&, d]() {
+            // device d of the visible ones, starting at the calling thread's current device
+            const int dev = (c->device + d) % visible;
+            GrowDevBuf dPcm, dOut;
+            hipStream_t st = nullptr;
+            CtxRef dref;
+            bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreate(&st) == hipSuccess;
+            if (ok) ok = (dev == c->device) ? (dref = cref, true) : cached_context(cfg, &dref) == MFCC_OK;
+            std::string why = ok ? "" : (MFCCLastError()[0] ? MFCCLastError() : "no HIP device available (the library has no CPU path)");
+            for (;;) {
+                ListBatch *b = loadedQ.pop();
+                if (!b) break;
+                const double t0 = now_s();
+                if (!ok) {
+                    set_error("%s", why.c_str());
+                    b->rc = MFCC_E_DEVICE;
+                } else {
+                    b->rc = list_device_stage(dref.get(), *b, dPcm, dOut, st);
+                }
+                if (b->rc) b->message = MFCCLastError();
+                {
+                    std::lock_guard<std::mutex> g(tMu);
+                    tDev += now_s() - t0;
+                }
+                computedQ.push(b);
             }
-            if (b->rc) b->message = MFCCLastError();
-            tDev += now_s() - t0;
-            computedQ.push(b);
-        }
-        if (st) (void)hipStreamDestroy(st);
-        computedQ.push(nullptr);
-    });
+            if (st) (void)hipStreamDestroy(st);
+            computedQ.push(nullptr);
+        });
 
     std::thread writeThread([&]() {
-        for (;;) {
+        for (int finished = 0; finished < numDev;) {
             ListBatch *b = computedQ.pop();
-            if (!b) break;
+            if (!b) {
+                ++finished;
+                continue;
+            }
             const double t0 = now_s();
             if (b->rc) {
                 for (size_t i : b->idx) {
@@ -1897,12 +1921,12 @@ extern "C" int MFCCWapperList(const char *iniPath)
         else
             loadedQ.push(b);
     }
-    loadedQ.push(nullptr);
-    devThread.join();
+    for (int d = 0; d < numDev; ++d) loadedQ.push(nullptr);
+    for (auto &th : devThreads) th.join();
     writeThread.join();
     if (timing)
-        fprintf(stderr, "MFCCWapperList stages (busy seconds): read %.3f pack %.3f device %.3f write %.3f\n",
-                tRead, tPack, tDev, tWrite);
+        fprintf(stderr, "MFCCWapperList stages (busy seconds): read %.3f pack %.3f device %.3f (%d GPU%s) write %.3f\n",
+                tRead, tPack, tDev, numDev, numDev > 1 ? "s" : "", tWrite);
 
     int failed = 0;
     for (const ListItem &it : items)
@@ -1912,4 +1936,170 @@ extern "C" int MFCCWapperList(const char *iniPath)
         }
     if (failed) set_error("%d of %zu files failed", failed, items.size());
     return failed;
+}
+
+// ------------------------------------------------------------------------------------------
+// one long recording over several GPUs from one process
+// ------------------------------------------------------------------------------------------
+
+namespace {
+
+// All shard threads wait here; reusable.
+class ShardBarrier {
+public:
+    explicit ShardBarrier(int n) : n_(n) {}
+    void wait()
+    {
+        std::unique_lock<std::mutex> lock(mu_);
+        const int gen = gen_;
+        if (++count_ == n_) {
+            count_ = 0;
+            ++gen_;
+            cv_.notify_all();
+        } else {
+            cv_.wait(lock, [&] { return gen_ != gen; });
+        }
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int n_, count_ = 0, gen_ = 0;
+};
+
+} // namespace
+
+// The frame-sharded mode for one very long recording, driven from one process: shard g owns frames
+// [T g / S, T (g+1) / S), runs on its own GPU from its own host thread, recomputes the halo frames
+// its regression deltas need (MFCCShardGeometry), and the shards exchange only the integer channel
+// sums (zeroMeanSigFlag) and the z-norm column sums (znormFlag): each shard's vector goes to the
+// host, every shard adds all of them in shard order (so all hold bit-identical totals, whatever the
+// timing) and goes on.  The per-file semantics are those of main.c:198-266 on the whole recording.
+extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, int channels, int bytesPerSample,
+                                    int64_t numSamples, int numShards, const int *devices, void *features,
+                                    int64_t *numFrames)
+{
+    if (numFrames) *numFrames = 0;
+    if (!cfgIn || numSamples < 0 || (numSamples > 0 && !pcm) || numShards < 0 || numShards > 64)
+        return set_error("bad argument to MFCCExtractRecording"), MFCC_E_ARG;
+    if (channels < 1 || channels > 2 || bytesPerSample < 1 || bytesPerSample > 4)
+        return set_error("unsupported PCM layout: %d channels x %d bytes", channels, bytesPerSample), MFCC_E_WAV;
+    const MFCCConfig cfg = *cfgIn;
+    int rc = validate_config(cfg);
+    if (rc) return rc;
+    int visible = 0, current = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1 || hipGetDevice(&current) != hipSuccess)
+        return set_error("no HIP device available (the library has no CPU path)"), MFCC_E_DEVICE;
+    const int S = numShards > 0 ? numShards : visible;
+    const int64_t T = MFCCNumFrames((long)numSamples, cfg.wlen, cfg.inc);
+    if (numFrames) *numFrames = T;
+    if (T == 0) return MFCC_OK;
+    if (!features) return set_error("NULL feature buffer"), MFCC_E_ARG;
+    const int step = MFCCStep(&cfg);
+    const size_t el = cfg.precision == MFCC_PREC_F64 ? 8 : 4;
+    const int64_t bpi = (int64_t)channels * bytesPerSample;
+    std::vector<std::array<int64_t, 4>> chanSums((size_t)S);
+    std::vector<std::vector<double>> colSums((size_t)S, std::vector<double>((size_t)2 * step + 1, 0.0));
+    std::vector<int> status((size_t)S, MFCC_OK);
+    std::vector<std::string> message((size_t)S);
+    std::atomic<bool> failed(false);
+    ShardBarrier barrier(S);
+
+    auto shard = [&](int g) {
+        const int dev = devices ? devices[g] : (current + g) % visible;
+        const int64_t fb = T * g / S, fe = T * (g + 1) / S;
+        int64_t sb = 0, sc = 0, rows = 0, ownBegin = 0, ownRows = 0;
+        int lead = 0;
+        MFCCShardGeometry(&cfg, numSamples, fb, fe, &sb, &sc, &rows, &ownBegin, &ownRows, &lead);
+        const bool empty = fe == fb;
+        // instants whose channel sums this shard contributes: a partition of the recording
+        const int64_t partBegin = g == 0 ? 0 : fb * cfg.inc, partEnd = g == S - 1 ? numSamples : fe * cfg.inc;
+        const int64_t upBegin = empty ? partBegin : std::min(sb, partBegin);
+        const int64_t upEnd = std::max(empty ? partEnd : sb + sc, partEnd);
+        CtxRef ctx;
+        DevBuf dPcm, dOut, dSums;
+        MFCCPlan *plan = nullptr;
+        hipStream_t st = nullptr;
+        auto fail = [&](int code) {
+            status[(size_t)g] = code;
+            message[(size_t)g] = MFCCLastError();
+            failed = true;
+        };
+        auto hip_ok = [&](hipError_t e) {
+            if (e == hipSuccess) return true;
+            set_error("HIP error %d (%s) in shard %d on device %d", (int)e, hipGetErrorString(e), g, dev);
+            fail(MFCC_E_DEVICE);
+            return false;
+        };
+        // phase 1: device, context, PCM upload, channel sums
+        bool ok = hip_ok(hipSetDevice(dev)) && hip_ok(hipStreamCreate(&st));
+        if (ok) {
+            const int r = cached_context(cfg, &ctx);
+            if (r) fail(r), ok = false;
+        }
+        if (ok) ok = hip_ok(hipMalloc(&dPcm.p, (size_t)std::max<int64_t>((upEnd - upBegin) * bpi, 16) + 16)) &&
+                     hip_ok(hipMalloc(&dSums.p, ((size_t)2 * step + 1) * sizeof(double) + 64)) &&
+                     hip_ok(hipMemcpyAsync(dPcm.p, static_cast<const unsigned char *>(pcm) + upBegin * bpi,
+                                           (size_t)((upEnd - upBegin) * bpi), hipMemcpyHostToDevice, st));
+        chanSums[(size_t)g] = {0, 0, 0, 0};
+        if (ok && cfg.zeroMeanSigFlag) {
+            const int r = MFCCChannelSums(ctx.get(), dPcm.p, channels, bytesPerSample, partBegin - upBegin,
+                                          partEnd - partBegin, static_cast<int64_t *>(dSums.p), st);
+            if (r) fail(r), ok = false;
+            else
+                ok = hip_ok(hipMemcpyAsync(chanSums[(size_t)g].data(), dSums.p, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st)) &&
+                     hip_ok(hipStreamSynchronize(st));
+        }
+        barrier.wait();
+        // phase 2: plan, static features and deltas, column sums
+        int64_t total2[4] = {0, 0, 0, 0};
+        for (int k = 0; k < S; ++k)
+            for (int j = 0; j < 4; ++j) total2[j] += chanSums[(size_t)k][(size_t)j];
+        ok = ok && !failed;
+        if (ok && !empty) {
+            int r = MFCCPlanCreateShard(ctx.get(), channels, bytesPerSample, numSamples, fb, fe,
+                                        cfg.zeroMeanSigFlag ? total2 : nullptr, &plan);
+            if (!r) ok = hip_ok(hipMalloc(&dOut.p, (size_t)rows * step * el));
+            const unsigned char *shardPcm = static_cast<const unsigned char *>(dPcm.p) + (sb - upBegin) * bpi;
+            if (!r && ok) r = MFCCExtractDevice(ctx.get(), plan, shardPcm, (size_t)(sc * bpi), dOut.p, st);
+            if (!r && ok && cfg.znormFlag) {
+                r = MFCCShardColumnSums(ctx.get(), plan, dOut.p, static_cast<double *>(dSums.p), st);
+                if (!r)
+                    ok = hip_ok(hipMemcpyAsync(colSums[(size_t)g].data(), dSums.p, ((size_t)2 * step + 1) * sizeof(double),
+                                               hipMemcpyDeviceToHost, st)) &&
+                         hip_ok(hipStreamSynchronize(st));
+            }
+            if (r) fail(r), ok = false;
+        }
+        barrier.wait();
+        // phase 3: normalise with the totals, own rows back to the host
+        ok = ok && !failed;
+        if (ok && !empty) {
+            int r = MFCC_OK;
+            if (cfg.znormFlag) {
+                std::vector<double> tot((size_t)2 * step + 1, 0.0);
+                for (int k = 0; k < S; ++k)
+                    for (size_t j = 0; j < tot.size(); ++j) tot[j] += colSums[(size_t)k][j];
+                ok = hip_ok(hipMemcpyAsync(dSums.p, tot.data(), tot.size() * sizeof(double), hipMemcpyHostToDevice, st)) &&
+                     hip_ok(hipStreamSynchronize(st)); // (tot leaves scope)
+                if (ok) r = MFCCShardNormalize(ctx.get(), plan, dOut.p, static_cast<const double *>(dSums.p), st);
+            }
+            if (!r && ok)
+                ok = hip_ok(hipMemcpyAsync(static_cast<unsigned char *>(features) + (size_t)fb * step * el,
+                                           static_cast<const unsigned char *>(dOut.p) + (size_t)ownBegin * step * el,
+                                           (size_t)ownRows * step * el, hipMemcpyDeviceToHost, st)) &&
+                     hip_ok(hipStreamSynchronize(st));
+            if (r) fail(r);
+        }
+        if (plan) MFCCPlanDestroy(plan);
+        if (st) (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> threads;
+    for (int g = 1; g < S; ++g) threads.emplace_back(shard, g);
+    shard(0);
+    for (auto &th : threads) th.join();
+    (void)hipSetDevice(current);
+    for (int g = 0; g < S; ++g)
+        if (status[(size_t)g] != MFCC_OK) return set_error("shard %d: %s", g, message[(size_t)g].c_str()), status[(size_t)g];
+    return MFCC_OK;
 }

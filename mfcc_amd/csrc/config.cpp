@@ -69,6 +69,7 @@ static int apply_key(MFCCConfig *c, const char *section, const char *name, const
         c->fileList[MFCC_MAX_PATH - 1] = 0;
     }
     else if (is("IO", "numThreads")) c->numThreads = atoi(value);
+    else if (is("IO", "numDevices")) c->numDevices = atoi(value);
     else if (is("IO", "precision")) c->precision = (!strcmp(value, "f64") || !strcmp(value, "1"));
     else if (is("MFCC", "fbankFlag")) c->fbankFlag = atoi(value);
     else if (is("MFCC", "bankNum")) c->bankNum = atoi(value);
@@ -139,6 +140,7 @@ extern "C" int MFCCConfigDefaults(MFCCConfig *cfg)
     cfg->delwin = 2;
     cfg->saveType = MFCC_SAVE_E;
     cfg->numThreads = 1;
+    cfg->numDevices = 0;
     cfg->precision = MFCC_PREC_F64; // the reference computes in double; single precision is the opt-in fast mode
     return MFCC_OK;
 }

@@ -343,16 +343,20 @@ def test_wapper_list_batches_mixed_layouts(oracle, tmp_path):
     for sec, keys in sections.items():
         text += "[%s]\n" % sec + "".join("%s = %s\n" % (k, kw[k]) for k in keys if k in kw)
     assert sum(k in kw for keys in sections.values() for k in keys) == len(kw)
-    ini.write_text(text + "[IO]\nsaveType = b\nnumThreads = 3\nfileList = %s\n" % lst)
     os.environ["MFCC_QUIET"] = "1"
-    assert ma.wapper_list(str(ini)) == 1
-    assert not (tmp_path / "f07.bin").exists()
     step = ma.step(cfg)
-    for i, (pcm, ch, bps) in expect.items():
-        got = np.fromfile(tmp_path / ("f%02d.bin" % i), dtype=np.float64).reshape(-1, step)
-        want = ma.wapper_mem(cfg, ma.wav_bytes(pcm, ch, bps, 16000))
-        assert got.shape == want.shape, i
-        assert np.array_equal(got, want, equal_nan=True), i
+    # one device thread, then three (the path a multi-GPU node takes: every thread draws batches)
+    for devices in ("", "numDevices = -3\n"):
+        ini.write_text(text + "[IO]\nsaveType = b\nnumThreads = 3\n%sfileList = %s\n" % (devices, lst))
+        for f in tmp_path.glob("*.bin"):
+            f.unlink()
+        assert ma.wapper_list(str(ini)) == 1
+        assert not (tmp_path / "f07.bin").exists()
+        for i, (pcm, ch, bps) in expect.items():
+            got = np.fromfile(tmp_path / ("f%02d.bin" % i), dtype=np.float64).reshape(-1, step)
+            want = ma.wapper_mem(cfg, ma.wav_bytes(pcm, ch, bps, 16000))
+            assert got.shape == want.shape, i
+            assert np.array_equal(got, want, equal_nan=True), i
     assert (tmp_path / "f13.bin").stat().st_size == 0  # shorter than one frame: no rows
     ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), expect[2][0], 2, 3)
     got = np.fromfile(tmp_path / "f02.bin", dtype=np.float64).reshape(-1, step)
@@ -753,3 +757,29 @@ def test_tonal_input_error_envelope(oracle, name):
             print("  %5.0f .. %5.0f dB: %7d values, max error %.3g" % (lo * 4.343, min(hi, 40) * 4.343, int(m.sum()), float(err[m].max())))
     assert float(err[below < 13.8].max()) <= 1e-4
     assert float(err.max()) <= 5e-3
+
+
+@pytest.mark.parametrize("zero_mean", [0, 1])
+def test_recording_over_several_shards_from_one_process(oracle, zero_mean):
+    """MFCCExtractRecording (the C entry point that drives one GPU and one host thread per frame
+    range): three shards on the one GPU of this box against the oracle on the whole recording, and
+    -- without z-norm, where nothing depends on the summation order -- bit for bit against one shard."""
+    kw = dict(CONFIGS["c5"], zeroMeanSigFlag=zero_mean)
+    n = 44100 * 3 + 555
+    pcm = _pcm(n, 2, 3, 91, 44100)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 2, 3)
+    for prec, f64 in ((ma.PREC_F32, False), (ma.PREC_F64, True)):
+        cfg = ma.make_config(precision=prec, **kw)
+        got = ma.extract_recording(cfg, pcm, 2, 3, num_shards=3, devices=[0, 0, 0])
+        assert got.shape == ref.shape
+        _compare(got.astype(np.float64), ref, kw, f64)
+    kw2 = dict(kw, znormFlag=0)
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw2)
+    one = ma.extract_recording(cfg, pcm, 2, 3, num_shards=1)
+    for shards in (2, 5):
+        many = ma.extract_recording(cfg, pcm, 2, 3, num_shards=shards, devices=[0] * shards)
+        assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
+    # more shards than frames, and a recording shorter than one frame
+    tiny = ma.extract_recording(cfg, pcm[:6 * 1764 * 2], 2, 3, num_shards=4, devices=[0] * 4)
+    assert tiny.shape[0] == ma.num_frames(1764 * 2, 1764, 882)
+    assert ma.extract_recording(cfg, pcm[:600], 2, 3, num_shards=2, devices=[0, 0]).shape[0] == 0

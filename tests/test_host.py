@@ -99,9 +99,10 @@ def test_ini_readme_layout_and_errors(tmp_path):
     p = tmp_path / "c.ini"
     p.write_text("; comment\n[Frame]\nsampleRate=16000\nzeroMeanSigFlag = 1\nwlen : 400\n"
                  "[Regression]\nznormFlag = 1 ; note\n[IO]\nfileList = a b.txt\nsaveType = n\nnumThreads = 4\n"
-                 "precision = f64\n")
+                 "precision = f64\nnumDevices = 2\n")
     cfg = ma.config_from_ini(str(p))
     assert (cfg.zeroMeanSigFlag, cfg.znormFlag, cfg.saveType, cfg.numThreads) == (1, 1, ma.SAVE_N, 4)
+    assert cfg.numDevices == 2 and ma.make_config().numDevices == 0 and ma.make_config().precision == ma.PREC_F64
     assert cfg.fileList == b"a b.txt" and cfg.precision == ma.PREC_F64 and cfg.wlen == 400
     for letter, code in (("f", ma.SAVE_F), ("e", ma.SAVE_E), ("n", ma.SAVE_N), ("b", ma.SAVE_B), ("zz", ma.SAVE_E)):
         p.write_text("[Frame]\nsaveType = %s\n" % letter)  # main.c:76-80: anything else -> e
