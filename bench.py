@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--utts", type=int, default=0, help="utterances per GPU (0 = workload default)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--tune", default="", help="plan-heuristic overrides for measurements, key=value,... (MFCCDebugTuning)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     args = ap.parse_args()
@@ -216,6 +217,8 @@ def main():
     import mfcc_amd as ma
     from mfcc_amd.presets import CONFIGS
 
+    if args.tune:
+        ma.tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tune.split(",") if item)})
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -295,6 +295,13 @@ double MFCCMel(int k, double fres);
 int MFCCPlanEnableTiming(MFCCPlan *plan, int on);
 float MFCCPlanLastKernelMs(MFCCPlan *plan);
 
+/* No counterpart in the reference.  Debug / tuning override of one plan heuristic for the plans
+ * created afterwards in this process (measurement scripts, tests that must reach one kernel
+ * variant): keys noLean, pplog, tileFrames, tileTables, tileBlocks, melPieces, noMelMatrix,
+ * blocksPerCu, noUttFinish, noFinishReg, noFusedDelta, leanChunk, debug; key NULL resets all.  The
+ * library reads no tuning from the environment. */
+int MFCCDebugTuning(const char *key, int value);
+
 /* Deterministic synthetic PCM used by the benchmark and the tests (integer-only generator, so the
  * bytes are identical on every machine): triangular-pdf noise from a 64-bit LCG seeded with
  * `seed`, optional integer-table tone of `toneHz` at -12 dBFS added; 16- or 24-bit samples.

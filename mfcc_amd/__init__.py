@@ -70,7 +70,7 @@ EXPORTS = [
     "MFCCPlanDestroy", "MFCCShardGeometry", "MFCCPlanTotalRows", "MFCCPlanRowOffset", "MFCCPlanNumFrames",
     "MFCCPlanSampleBegin", "MFCCPlanSampleCount", "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows",
     "MFCCExtractDevice", "MFCCExtractRecording", "MFCCColumnSumsNoAlloc", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
-    "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCSynthPcm", "MFCCSynthPcmAt", "MFCCFormatValue",
+    "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCDebugTuning", "MFCCSynthPcm", "MFCCSynthPcmAt", "MFCCFormatValue",
     "MFCCFFTDevice", "MFCCRealftDevice", "MFCCWave2FBankDevice", "MFCCFBank2MFCCDevice", "MFCCMel",
     "MFCCFBankTables", "MFCCWave2FBankTablesDevice", "MFCCFBank2MFCCDirectDevice",
 ]
@@ -136,6 +136,7 @@ def lib():
     L.MFCCShardNormalize.argtypes = [vp, vp, vp, vp, vp]
     L.MFCCChannelSums.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp]
     L.MFCCPlanEnableTiming.argtypes = [vp, C.c_int]
+    L.MFCCDebugTuning.argtypes = [C.c_char_p, C.c_int]
     L.MFCCPlanLastKernelMs.argtypes = [vp]
     L.MFCCPlanLastKernelMs.restype = C.c_float
     L.MFCCSynthPcm.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_int,
@@ -218,6 +219,15 @@ def compat_lib():
 def _check(rc):
     if rc != 0:
         raise MFCCError(rc, lib().MFCCLastError().decode(errors="replace"))
+
+
+def tuning(**kw):
+    """MFCCDebugTuning: overrides of the plan heuristics for plans created afterwards (tuning() with
+    no arguments resets all)."""
+    if not kw:
+        _check(lib().MFCCDebugTuning(None, 0))
+    for k, v in kw.items():
+        _check(lib().MFCCDebugTuning(k.encode(), int(v)))
 
 
 def make_config(**kw):

@@ -18,6 +18,8 @@
 #include <thread>
 #include <vector>
 
+#include <rocprofiler-sdk-roctx/roctx.h>
+
 #include "mfcc_host.h"
 
 using namespace mfcc;
@@ -50,6 +52,12 @@ struct DeviceScope {
     DeviceScope(const DeviceScope &) = delete;
     DeviceScope &operator=(const DeviceScope &) = delete;
 };
+// Named range in rocprofv3 --marker-trace timelines (host side: the enclosed calls are asynchronous).
+struct TraceRange {
+    explicit TraceRange(const char *name) { roctxRangePush(name); }
+    ~TraceRange() { roctxRangePop(); }
+};
+
 #define DEVICE_SCOPE(dev)            \
     DeviceScope deviceScope_(dev);   \
     HIP_TRY(deviceScope_.err)
@@ -88,6 +96,7 @@ struct MFCCPlan {
     int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
     bool lean256 = false; // mode 2 run by the pipelined 256-point kernel
     int leanWaves = 0;    // ... with this many waves per workgroup
+    int leanChunk = 0;    // ... tiles per chunk override (0: heuristic, -1: fixed ranges)
     std::vector<float> melW;
     std::vector<int32_t> melMeta;
     int melSteps = 0;
@@ -221,30 +230,54 @@ extern "C" int MFCCContextTables(const MFCCContext *c, int *fftN, int *klo, int 
     return MFCC_OK;
 }
 
-extern "C" int MFCCHostTables(const MFCCConfig *cfgIn, int *fftN, int *klo, int *khi, double *cf,
-                              int *loChan, double *loWt, double *window, char *passband, size_t cap)
+// ------------------------------------------------------------------------------------------
+// Debug / tuning overrides of the plan heuristics.  Process-wide, set through MFCCDebugTuning only
+// (never read from the environment, so a caller's environment cannot change which kernel runs):
+// measurement scripts and the tests that must reach a specific kernel variant use it.
+// ------------------------------------------------------------------------------------------
+
+namespace {
+struct Tuning {
+    int noLean = 0;        // never take the lean instantiations
+    int pplog = 0;         // complex points per lane = 2^pplog (0: heuristic)
+    int tileFrames = 0, tileTables = 0, tileBlocks = 0; // general kernel tile: frames, tables in LDS, workgroups per CU
+    int melPieces = 0;     // parts a mel segment is cut into (0: heuristic)
+    int noMelMatrix = 0;   // no matrix-core mel filterbank
+    int blocksPerCu = 0;   // resident workgroups per CU (0: heuristic)
+    int noUttFinish = 0;   // deltas / z-norm by the row-block kernels even for short utterances
+    int noFinishReg = 0;   // whole-utterance finishing kernel without its register variant
+    int noFusedDelta = 0;  // one regression pass per order
+    int leanChunk = 0;     // tiles per chunk of the pipelined 256-point kernel (0: heuristic, -1: fixed ranges)
+    int debug = 0;         // print the plan's choices to stderr
+};
+Tuning g_tune;
+std::mutex g_tuneMu;
+Tuning tuning()
 {
-    if (!cfgIn) return set_error("NULL argument"), MFCC_E_ARG;
-    MFCCConfig cfg = *cfgIn;
-    if (cfg.fbankFlag) {
-        cfg.MFCCNum = cfg.bankNum;
-        cfg.MFCC0thFlag = 0;
+    std::lock_guard<std::mutex> g(g_tuneMu);
+    return g_tune;
+}
+} // namespace
+
+extern "C" int MFCCDebugTuning(const char *key, int value)
+{
+    std::lock_guard<std::mutex> g(g_tuneMu);
+    if (!key) {
+        g_tune = Tuning();
+        return MFCC_OK;
     }
-    int rc = validate_config(cfg);
-    if (rc) return rc;
-    Tables t;
-    if ((rc = build_tables(cfg, t))) return rc;
-    if (fftN) *fftN = t.fftN;
-    if (klo) *klo = t.klo;
-    if (khi) *khi = t.khi;
-    if (cf) std::copy(t.cf.begin(), t.cf.end(), cf);
-    if (loChan) std::copy(t.loChan.begin(), t.loChan.end(), loChan);
-    if (loWt) std::copy(t.loWt.begin(), t.loWt.end(), loWt);
-    if (window) std::copy(t.window.begin(), t.window.end(), window);
-    if (passband)
-        snprintf(passband, cap, "FFT passband %d to %d out of 1 to %d\nMel passband %f to %f\n", t.klo,
-                 t.khi, t.nc, t.mlo, t.mhi); /* mfcc.c:74-75 */
-    return MFCC_OK;
+    const struct { const char *name; int Tuning::*field; } keys[] = {
+        {"noLean", &Tuning::noLean}, {"pplog", &Tuning::pplog}, {"tileFrames", &Tuning::tileFrames},
+        {"tileTables", &Tuning::tileTables}, {"tileBlocks", &Tuning::tileBlocks}, {"melPieces", &Tuning::melPieces},
+        {"noMelMatrix", &Tuning::noMelMatrix}, {"blocksPerCu", &Tuning::blocksPerCu}, {"noUttFinish", &Tuning::noUttFinish},
+        {"noFinishReg", &Tuning::noFinishReg}, {"noFusedDelta", &Tuning::noFusedDelta}, {"leanChunk", &Tuning::leanChunk},
+        {"debug", &Tuning::debug}};
+    for (const auto &k : keys)
+        if (!strcmp(key, k.name)) {
+            g_tune.*(k.field) = value;
+            return MFCC_OK;
+        }
+    return set_error("MFCCDebugTuning: unknown key %s", key), MFCC_E_ARG;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -256,6 +289,7 @@ extern "C" int MFCCHostTables(const MFCCConfig *cfgIn, int *fftN, int *klo, int 
 static int choose_tile(MFCCPlan *p)
 {
     const MFCCContext *c = p->ctx;
+    const Tuning tune = tuning();
     const int V = c->cfg.vecNum, log2nc = c->tab.log2nc, prec = c->cfg.precision;
     const int nc = c->tab.nc, P = c->cfg.bankNum;
     // complex points per lane = 2^pplog: for the general kernel 8 points (radix-8 stages) measured
@@ -265,10 +299,9 @@ static int choose_tile(MFCCPlan *p)
     const bool leanCand = prec == MFCC_PREC_F32 && p->channels == 1 && p->bps == 2 && V == 1 &&
                           c->cfg.inc % 2 == 0 && !c->cfg.zeroCrossingFlag && !c->cfg.brightFlag &&
                           !c->cfg.subBandEFlag && !c->cfg.fftLength && !c->cfg.zeroMeanSigFlag &&
-                          !getenv("MFCC_NO_LEAN");
+                          !tune.noLean;
     int pplog = (front_variant_exists(log2nc, 3) && !leanCand) ? 3 : 4;
-    if (const char *e = getenv("MFCC_PPLOG")) // tuning aid
-        if (front_variant_exists(log2nc, atoi(e))) pplog = atoi(e);
+    if (tune.pplog > 0 && front_variant_exists(log2nc, tune.pplog)) pplog = tune.pplog;
     p->pplog = pplog;
     const int teams = front_teams(log2nc, pplog);
     const int groups = front_groups(log2nc, pplog) / teams; // frames in flight per team
@@ -279,7 +312,7 @@ static int choose_tile(MFCCPlan *p)
     // spare (one round must still hold every part): the parts are summed by different lanes.
     int pieces = 1;
     while (pieces < 4 && (pieces + 1) * (c->cfg.bankNum + 1) <= lanes) ++pieces;
-    if (getenv("MFCC_MEL_PIECES")) pieces = std::max(1, std::min(4, atoi(getenv("MFCC_MEL_PIECES")))); // tuning aid
+    if (tune.melPieces > 0) pieces = std::max(1, std::min(4, tune.melPieces));
     p->melPieces = pieces;
     int zPitch = (std::max(2 * (nc + nc / 16), 2 * nc + std::max(2 * pieces * (c->cfg.bankNum + 1), 16) + 2 * c->cfg.subBandEFlag) + 3) & ~3;
     p->zPitch = zPitch;
@@ -374,7 +407,7 @@ static int choose_tile(MFCCPlan *p)
                 e[1] = se[sg];
                 e[2] = sg;
             }
-        if (getenv("MFCC_DEBUG")) {
+        if (tune.debug) {
             int total = 0;
             for (int r = 0; r < p->maxSeg; ++r) total += roundCost(inRound[r]);
             fprintf(stderr, "mfcc plan: mel rounds %d, modelled LDS cycles per frame pair %d\n", p->maxSeg, total);
@@ -384,7 +417,7 @@ static int choose_tile(MFCCPlan *p)
     // channels ("quad") and a contiguous run of the bins that touch them.  Possible when a frame fills at most a quarter wave
     // (256..1024 complex points at 16 points per lane) and every run fits kMelSteps.
     p->melSteps = 0;
-    if (leanCand && pplog == 4 && log2nc >= 8 && log2nc <= 10 && !getenv("MFCC_NO_MELM")) {
+    if (leanCand && pplog == 4 && log2nc >= 8 && log2nc <= 10 && !tune.noMelMatrix) {
         const int P1 = P + 1, NQ = (P + 3) / 4;
         std::vector<int> sb(P1, 0), se(P1, 0);
         for (int k = 0; k < nc; ++k) {
@@ -502,7 +535,7 @@ static int choose_tile(MFCCPlan *p)
             // frame slots 8 banks apart: work-area pitch = 8 (mod 32) elements
             zPitch = ((zPitch + 23) & ~31) + 8;
             p->zPitch = zPitch;
-            if (getenv("MFCC_DEBUG")) fprintf(stderr, "mfcc plan: matrix-core mel, %d steps (longest run %d)\n", steps, longest);
+            if (tune.debug) fprintf(stderr, "mfcc plan: matrix-core mel, %d steps (longest run %d)\n", steps, longest);
         }
     }
     const size_t el = prec == MFCC_PREC_F64 ? 8 : 4;
@@ -557,13 +590,10 @@ static int choose_tile(MFCCPlan *p)
         }
     }
     if (!bestFt) useTeams = teams;
-    if (const char *e = getenv("MFCC_TILE")) { // tuning aid: "<framesPerTile>,<tablesInLds>,<workgroupsPerCu>"
-        int ft = 0, tab = 0, blocks = 0;
-        if (sscanf(e, "%d,%d,%d", &ft, &tab, &blocks) == 3 && ft > 0 && blocks > 0) {
-            bestFt = ft;
-            bestTab = tab != 0;
-            bestBlocks = blocks;
-        }
+    if (tune.tileFrames > 0 && tune.tileBlocks > 0) {
+        bestFt = tune.tileFrames;
+        bestTab = tune.tileTables != 0;
+        bestBlocks = tune.tileBlocks;
     }
     if (!bestFt)
         return set_error("wlen %d / fftN %d needs more than 160 KiB of LDS per workgroup",
@@ -601,6 +631,7 @@ static int choose_tile(MFCCPlan *p)
             if (bytes > kLds) continue;
             p->lean256 = true;
             p->leanWaves = waves;
+            p->leanChunk = tune.leanChunk;
             p->framesPerTile = ft;
             p->rowPitch = rowPitchL;
             p->rowTail = 0;
@@ -613,24 +644,24 @@ static int choose_tile(MFCCPlan *p)
             p->activeTeams = waves;
             p->ldsBytes = bytes;
             p->blocksPerCu = 1;
-            if (getenv("MFCC_DEBUG"))
+            if (tune.debug)
                 fprintf(stderr, "mfcc plan: pipelined 256-point kernel, %d waves per workgroup, LDS %zu B\n", waves, bytes);
         }
         if (p->lean256) return MFCC_OK;
     }
     const int occ = front_occupancy(prec, log2nc, pplog, bestTab, p->mode, p->ldsBytes);
-    if (getenv("MFCC_DEBUG"))
+    if (tune.debug)
         fprintf(stderr, "mfcc plan: points/lane %d, teams %d, mode %d, framesPerTile %d, tables in LDS %d, LDS %zu B, workgroups/CU planned %d, runtime says %d\n",
                 1 << pplog, teams, p->mode, bestFt, (int)bestTab, p->ldsBytes, p->blocksPerCu, occ);
     if (occ > 0 && occ < p->blocksPerCu) p->blocksPerCu = occ;
-    if (const char *e = getenv("MFCC_BLOCKS_PER_CU")) // tuning aid: resident workgroups per CU
-        if (atoi(e) > 0) p->blocksPerCu = atoi(e);
+    if (tune.blocksPerCu > 0) p->blocksPerCu = tune.blocksPerCu;
     return MFCC_OK;
 }
 
 static int finish_plan(MFCCPlan *p)
 {
     MFCCContext *c = p->ctx;
+    const Tuning tune = tuning();
     int rc = choose_tile(p);
     if (rc) return rc;
     std::vector<int32_t> tileUtt, chunkUtt, regUtt;
@@ -739,7 +770,7 @@ static int finish_plan(MFCCPlan *p)
     // LDS budget (two workgroups per CU) beside the sub-tile buffers.
     p->uttFinish = false;
     if (!p->shard && c->cfg.regreOrder <= 3 && (c->cfg.regreOrder >= 2 || c->cfg.znormFlag) && c->vSize <= kBlock &&
-        p->totalRows > 0 && !getenv("MFCC_NO_UTT_FINISH")) {
+        p->totalRows > 0 && !tune.noUttFinish) {
         const size_t elb = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
         int64_t maxFrames = 1;
         for (const UttDesc &d : p->utts) maxFrames = std::max<int64_t>(maxFrames, d.numFrames);
@@ -758,13 +789,13 @@ static int finish_plan(MFCCPlan *p)
         }
         if (p->uttFinish) { // register variant: sub-tiles of rowLanes rows, at most kFinishRegRows per lane
             const int rowLanes = kFinishBlock / std::min(kFinishBlock, c->vSize);
-            p->finRegRows = (maxFrames <= (int64_t)kFinishRegRows * rowLanes && !getenv("MFCC_NO_FINISH_REG")) ? 1 : 0;
+            p->finRegRows = (maxFrames <= (int64_t)kFinishRegRows * rowLanes && !tune.noFinishReg) ? 1 : 0;
             // (its two first-delta buffers of rowLanes + 2 delwin rows must fit where the sub-tile buffers are)
             if (p->finRegRows && 2 * (rowLanes + 2 * c->cfg.delwin) * c->vSize >
                                      (p->finSubRows + 2 * c->cfg.delwin) * c->vSize + p->finSubRows * c->step)
                 p->finRegRows = 0;
         }
-        if (getenv("MFCC_DEBUG"))
+        if (tune.debug)
             fprintf(stderr, "mfcc plan: deltas / z-norm by %s (longest utterance %lld frames, %zu B of LDS)\n",
                     !p->uttFinish ? "row blocks" : (p->finRegRows ? "whole-utterance kernel, registers" : "whole-utterance kernel, two sweeps"),
                     (long long)maxFrames, p->finLds);
@@ -774,7 +805,7 @@ static int finish_plan(MFCCPlan *p)
     // Fused delta (+ statistics) pass: orders 2 and 3, rows of at most one workgroup of columns,
     // two LDS tiles of (subRows + 2 halo) rows within 64 KiB.
     p->deltaSubRows = 0;
-    if (!p->uttFinish && c->cfg.regreOrder >= 2 && c->vSize <= kBlock && !getenv("MFCC_NO_FUSED_DELTA")) {
+    if (!p->uttFinish && c->cfg.regreOrder >= 2 && c->vSize <= kBlock && !tune.noFusedDelta) {
         const size_t elb = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
         const int halo = (std::min(c->cfg.regreOrder, 3) - 1) * c->cfg.delwin;
         for (int sr = 256; sr >= 8 && !p->deltaSubRows; sr /= 2) {
@@ -1077,7 +1108,9 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
             // than tiles
             const int waves = p->activeTeams;
             const int64_t teamsMax = (int64_t)p->numCus * waves;
-            const int chunk = p->numTiles <= teamsMax ? 1 : (int)std::max<int64_t>(2, std::min<int64_t>(32, p->numTiles / (8 * teamsMax)));
+            int chunk = p->numTiles <= teamsMax ? 1 : (int)std::max<int64_t>(2, std::min<int64_t>(32, p->numTiles / (8 * teamsMax)));
+            if (p->leanChunk > 0) chunk = p->leanChunk;
+            if (p->leanChunk < 0) chunk = (int)((p->numTiles + teamsMax - 1) / teamsMax);
             const int64_t chunks = (p->numTiles + chunk - 1) / chunk;
             const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((chunks + waves - 1) / waves, p->numCus));
             a.numUtts = p->numUtts;
@@ -1223,6 +1256,7 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
         if (d.numFrames > 0 && (uint64_t)(d.byteOff + (int64_t)d.numInstants * bpi) > (uint64_t)pcmBytes)
             return set_error("PCM buffer of %zu bytes is shorter than the plan needs", pcmBytes), MFCC_E_ARG;
     DEVICE_SCOPE(c->device);
+    TraceRange range("MFCCExtractDevice");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
     if (c->cfg.zeroMeanSigFlag && !p->shard) {
@@ -1691,10 +1725,16 @@ int list_device_stage(MFCCContext *c, ListBatch &b, GrowDevBuf &dPcm, GrowDevBuf
     if ((rc = b.hOut.ensure(outBytes))) return rc;
     if ((rc = dPcm.ensure(b.pcmBytes + 16))) return rc;
     if ((rc = dOut.ensure(outBytes))) return rc;
-    HIP_TRY(hipMemcpyAsync(dPcm.p, b.hPcm.p, b.pcmBytes, hipMemcpyHostToDevice, st));
+    {
+        TraceRange r("mfcc list: H2D");
+        HIP_TRY(hipMemcpyAsync(dPcm.p, b.hPcm.p, b.pcmBytes, hipMemcpyHostToDevice, st));
+    }
     if ((rc = MFCCExtractDevice(c, plan, dPcm.p, b.pcmBytes, dOut.p, st))) return rc;
-    HIP_TRY(hipMemcpyAsync(b.hOut.p, dOut.p, outBytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    {
+        TraceRange r("mfcc list: D2H + wait");
+        HIP_TRY(hipMemcpyAsync(b.hOut.p, dOut.p, outBytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     return MFCC_OK;
 }
 
@@ -1807,6 +1847,9 @@ extern "C" int MFCCWapperList(const char *iniPath)
                     items[i].message = b->message;
                 }
             } else {
+                if (!quiet) /* main.c:252,274, once per file */
+                    for (size_t u = 0; u < b->idx.size(); ++u) printf("post-processing...\nwriting the doc...\n");
+                TraceRange r("mfcc list: write");
                 parallel_for(b->idx.size(), nth, [&](size_t u) {
                     ListItem &it = items[b->idx[u]];
                     const size_t n = (size_t)b->frames[u] * c->step;
@@ -1845,8 +1888,14 @@ extern "C" int MFCCWapperList(const char *iniPath)
         while (end < items.size() && bytes < kBatchPcm && end - cursor < kBatchFiles) {
             ListItem &it = items[end];
             if (it.status == MFCC_OK) {
-                if (!quiet && !it.announced) /* main.c:180 */
+                if (!quiet && !it.announced) { /* main.c:180,184-187 */
                     printf("Convert %s to %s\n", it.src.c_str(), it.dst.c_str());
+                    printf("including : \nMFCCNum\t%d\nenergyFlag %d\nzeroCrossingFlag %d\nbrightFlag %d\nsubBandEFlag %d\n",
+                           c->M, cfg.energyFlag, cfg.zeroCrossingFlag, cfg.brightFlag, cfg.subBandEFlag);
+                    printf("the frame feature dimension is %d\n", c->step);
+                    printf("order %d\n", cfg.regreOrder);
+                    printf("start...\n");
+                }
                 it.announced = true;
                 if (!it.file.empty()) {
                     bytes += it.file.size();
@@ -1892,6 +1941,8 @@ extern "C" int MFCCWapperList(const char *iniPath)
                        outBytes >= kBatchOut) {
                 break;
             }
+            if (!quiet) /* main.c:212 */
+                printf("total coef size: %ld\n", (long)MFCCNumFrames(it.w.numSamples, cfg.wlen, cfg.inc) * c->step);
             b->idx.push_back(i);
             b->off.push_back((int64_t)b->pcmBytes);
             b->ns.push_back(it.w.numSamples);

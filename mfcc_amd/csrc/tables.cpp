@@ -129,3 +129,32 @@ int build_tables(const MFCCConfig &cfg, Tables &t)
 }
 
 } // namespace mfcc
+
+using namespace mfcc;
+
+extern "C" int MFCCHostTables(const MFCCConfig *cfgIn, int *fftN, int *klo, int *khi, double *cf,
+                              int *loChan, double *loWt, double *window, char *passband, size_t cap)
+{
+    if (!cfgIn) return set_error("NULL argument"), MFCC_E_ARG;
+    MFCCConfig cfg = *cfgIn;
+    if (cfg.fbankFlag) {
+        cfg.MFCCNum = cfg.bankNum;
+        cfg.MFCC0thFlag = 0;
+    }
+    int rc = validate_config(cfg);
+    if (rc) return rc;
+    Tables t;
+    if ((rc = build_tables(cfg, t))) return rc;
+    if (fftN) *fftN = t.fftN;
+    if (klo) *klo = t.klo;
+    if (khi) *khi = t.khi;
+    if (cf) std::copy(t.cf.begin(), t.cf.end(), cf);
+    if (loChan) std::copy(t.loChan.begin(), t.loChan.end(), loChan);
+    if (loWt) std::copy(t.loWt.begin(), t.loWt.end(), loWt);
+    if (window) std::copy(t.window.begin(), t.window.end(), window);
+    if (passband)
+        snprintf(passband, cap, "FFT passband %d to %d out of 1 to %d\nMel passband %f to %f\n", t.klo,
+                 t.khi, t.nc, t.mlo, t.mhi); /* mfcc.c:74-75 */
+    return MFCC_OK;
+}
+

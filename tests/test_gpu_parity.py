@@ -20,6 +20,13 @@ from util import assert_static_close, column_kinds, run_product_batch
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture
+def tuning():
+    """ma.tuning for one test: every override is reset afterwards."""
+    yield ma.tuning
+    ma.tuning()
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -59,11 +66,11 @@ def _compare(got, ref, kw, f64):
 @pytest.mark.parametrize("finish", ["utterance", "blocks"])
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 @pytest.mark.parametrize("name", ["c2", "c3", "c4", "c1a", "c1b", "c5"])
-def test_named_configs_match_oracle(oracle, name, precision, finish, monkeypatch):
+def test_named_configs_match_oracle(oracle, name, precision, finish, tuning):
     """finish: deltas and z-norm by the whole-utterance kernel (short utterances) or by the
-    row-block kernels (what long utterances take; forced here through MFCC_NO_UTT_FINISH)."""
+    row-block kernels (what long utterances take; forced here through the noUttFinish tuning key)."""
     if finish == "blocks":
-        monkeypatch.setenv("MFCC_NO_UTT_FINISH", "1")
+        tuning(noUttFinish=1)
     kw = CONFIGS[name]
     ch, bps = _layout(kw)
     n = kw["sampleRate"] + 123  # ~1 s: several tiles, first (general) and later (fast) unpack paths
@@ -130,13 +137,13 @@ def test_lean_kernel_modes(oracle, wlen, bank, cepstral):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MFCC_FUZZ_SEEDS", "48"))))
-def test_random_configurations(oracle, seed, monkeypatch):
+def test_random_configurations(oracle, seed, tuning):
     """Seeded random walk over the option space (frame geometry, channel layouts, feature flags,
     delta orders and windows, z-norm, batches of ragged utterances at odd byte offsets): whichever
     kernel mode, tile geometry and delta path the plan picks must agree with the oracle.  Every
     third seed takes the row-block delta / z-norm kernels instead of the whole-utterance one."""
     if seed % 3 == 2:
-        monkeypatch.setenv("MFCC_NO_UTT_FINISH", "1")
+        tuning(noUttFinish=1)
     rng = np.random.default_rng(1000 + seed)
     sr = int(rng.choice([8000, 16000, 44100]))
     wlen = int(rng.choice([64, 200, 256, 400, 441, 512, 800, 1024, 1764, 2048]))
@@ -175,12 +182,12 @@ def test_random_configurations(oracle, seed, monkeypatch):
 
 
 @pytest.mark.parametrize("finish", ["utterance", "blocks", "too long"])
-def test_ragged_batch_and_edge_lengths(oracle, finish, monkeypatch):
+def test_ragged_batch_and_edge_lengths(oracle, finish, tuning):
     """Empty, shorter than a window, exactly one window, one sample short of two frames, long;
     with the whole-utterance finishing kernel, with the row-block kernels forced, and with one
     utterance too long for the former (which moves the whole plan to the latter)."""
     if finish == "blocks":
-        monkeypatch.setenv("MFCC_NO_UTT_FINISH", "1")
+        tuning(noUttFinish=1)
     kw = CONFIGS["c3"]
     lens = [0, 1, 399, 400, 559, 560, 561, 5000, 16000, 401, 33333] + ([400 + 160 * 2500] if finish == "too long" else [])
     pcms = [_pcm(n, 1, 2, 100 + i, 16000) for i, n in enumerate(lens)]
@@ -656,13 +663,13 @@ def test_init_fbank_with_warping_and_double_fft(oracle):
 
 @pytest.mark.parametrize("name,frames,force_sweeps", [("c3", 1000, False), ("c3", 1100, False), ("c3", 97, True),
                                                       ("c1a", 100, False), ("c1a", 60, True), ("c3", 1400, False)])
-def test_whole_utterance_finish_variants(oracle, name, frames, force_sweeps, monkeypatch):
+def test_whole_utterance_finish_variants(oracle, name, frames, force_sweeps, tuning):
     """Both forms of the whole-utterance delta / z-norm kernel: deltas kept in registers (at most
     32 rows per lane: c3 1000 frames, c1a 100), the two-sweep form that longer utterances take (c3
-    1100 frames) or MFCC_NO_FINISH_REG forces, and the row-block kernels once the utterance no longer
+    1100 frames) or the noFinishReg tuning key forces, and the row-block kernels once the utterance no longer
     fits the LDS budget (c3 1400 frames); ragged batch with a one-frame and an empty utterance."""
     if force_sweeps:
-        monkeypatch.setenv("MFCC_NO_FINISH_REG", "1")
+        tuning(noFinishReg=1)
     kw = dict(CONFIGS[name], znormFlag=1)
     ch, bps = _layout(kw)
     lens = [kw["wlen"] + (frames - 1) * kw["inc"] + 3, kw["wlen"], kw["wlen"] - 1, kw["wlen"] + 7 * kw["inc"]]
@@ -783,3 +790,38 @@ def test_recording_over_several_shards_from_one_process(oracle, zero_mean):
     tiny = ma.extract_recording(cfg, pcm[:6 * 1764 * 2], 2, 3, num_shards=4, devices=[0] * 4)
     assert tiny.shape[0] == ma.num_frames(1764 * 2, 1764, 882)
     assert ma.extract_recording(cfg, pcm[:600], 2, 3, num_shards=2, devices=[0, 0]).shape[0] == 0
+
+
+def test_command_line_program_matches_the_per_file_entry_point(tmp_path):
+    """The drop-in program (`mfcc config.ini`, README.md:26) on an example/config.ini-shaped run:
+    its files equal MFCCWapper's byte for byte, and its console carries the reference's lines
+    (main.c:140,180,184-187,212,252,274; mfcc.c:74-75) unless MFCC_QUIET is set."""
+    import subprocess
+    kw = CONFIGS["c1a"]
+    exe = os.path.join(os.path.dirname(HERE), "tools", "mfcc")
+    lines = []
+    for i in range(3):
+        pcm = _pcm(44100 // 2 + 777 * i, 2, 3, 40 + i, 44100)
+        (tmp_path / ("a%d.wav" % i)).write_bytes(ma.wav_bytes(pcm, 2, 3, 44100))
+        lines.append("%s\t%s" % (tmp_path / ("a%d.wav" % i), tmp_path / ("a%d.fbank" % i)))
+    (tmp_path / "fileList.txt").write_text("\n".join(lines) + "\n")
+    ini = tmp_path / "config.ini"
+    ini.write_text("[Frame];\nsampleRate = 44100 ;\nhipassfre = 22050 ;\nlowpassfre = 10 ;\npreemphasise = 0 ;\n"
+                   "wlen = 1764 ;\ninc = 882 ;\nsaveType = f ;\nvecNum = 2 ;\nfileList = %s ;\n"
+                   "[MFCC];\nfbankFlag = 1 ;\nbankNum = 40 ;\nMFCCNum = -1 ;\nMFCC0thFlag = 0 ;\n"
+                   "[Others];\nenergyFlag = 1 ;\nzeroCrossingFlag = 1 ;\nbrightFlag = 1 ;\nsubBandEFlag = 8 ;\nfftLength = 0 ;\n"
+                   "[Regression];\nregreOrder = 3 ;\ndelwin = 9 ;\n" % (tmp_path / "fileList.txt"))
+    env = {k: v for k, v in os.environ.items() if k != "MFCC_QUIET"}
+    r = subprocess.run([exe, str(ini)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for text in ("finish reading the config.ini", "FFT passband 2 to 1024 out of 1 to 1024", "Mel passband 15.986084 to 3923.357581",
+                 "Convert %s to %s" % (tmp_path / "a0.wav", tmp_path / "a0.fbank"), "the frame feature dimension is 306",
+                 "order 3", "start...", "total coef size: %d" % (306 * ma.num_frames(44100 // 2, 1764, 882)),
+                 "post-processing...", "writing the doc..."):
+        assert text in r.stdout, text
+    cfg = ma.make_config(saveType=ma.SAVE_F, **kw)
+    for i in range(3):
+        ma.wapper(cfg, str(tmp_path / ("a%d.wav" % i)), str(tmp_path / ("w%d.fbank" % i)), want_features=False)
+        assert (tmp_path / ("a%d.fbank" % i)).read_bytes() == (tmp_path / ("w%d.fbank" % i)).read_bytes()
+    r = subprocess.run([exe, str(ini)], capture_output=True, text=True, env=dict(env, MFCC_QUIET="1"), timeout=120)
+    assert r.returncode == 0 and r.stdout == ""

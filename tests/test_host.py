@@ -339,3 +339,16 @@ def test_wav_rf64_and_extensible():
     with pytest.raises(ma.MFCCError) as e:
         ma.wav_info(extensible(3))
     assert e.value.code == ma.E_WAV
+
+
+def test_host_code_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """`make asan` builds the host sources (ini parser, WAV walk, writers, formatter, tables, PCM
+    generator) with -fsanitize=address,undefined around tests/host_checks.cpp; the run must pass its
+    own checks and leave both sanitizers silent (either one ends the program with a report)."""
+    import subprocess
+    src = os.path.join(ROOT, "mfcc_amd", "csrc")
+    subprocess.run(["make", "-C", src, "asan"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(src, "build", "host_asan"), str(tmp_path)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host_checks: ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
