@@ -95,6 +95,7 @@ struct MFCCPlan {
     size_t finLds = 0;
     int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
     bool lean256 = false; // mode 2 run by the pipelined 256-point kernel
+    bool wide1024 = false; // 24-bit stereo, 1024 complex points: run by k_wide1024 (raw PCM bytes in LDS)
     int leanWaves = 0;    // ... with this many waves per workgroup
     int leanChunk = 0;    // ... tiles per chunk override (0: heuristic, -1: fixed ranges)
     std::vector<float> melW;
@@ -286,7 +287,7 @@ extern "C" int MFCCDebugTuning(const char *key, int value)
 
 // LDS geometry of the static-feature kernel for this plan: frames per tile, whether the window /
 // twiddle / split tables get an LDS copy, and how many workgroups fit a CU.
-static int choose_tile(MFCCPlan *p)
+static int choose_tile(MFCCPlan *p, bool allowWide = true)
 {
     const MFCCContext *c = p->ctx;
     const Tuning tune = tuning();
@@ -300,8 +301,12 @@ static int choose_tile(MFCCPlan *p)
                           c->cfg.inc % 2 == 0 && !c->cfg.zeroCrossingFlag && !c->cfg.brightFlag &&
                           !c->cfg.subBandEFlag && !c->cfg.fftLength && !c->cfg.zeroMeanSigFlag &&
                           !tune.noLean;
-    int pplog = (front_variant_exists(log2nc, 3) && !leanCand) ? 3 : 4;
-    if (tune.pplog > 0 && front_variant_exists(log2nc, tune.pplog)) pplog = tune.pplog;
+    // 24-bit stereo with 1024 complex points: k_wide1024 (16 points per lane, wave-sized teams)
+    const bool wideCand = allowWide && prec == MFCC_PREC_F32 && !c->cfg.zeroMeanSigFlag && !c->cfg.fftLength &&
+                          p->totalRows < 0x7fffffffLL && !tune.noLean &&
+                          wide1024_applies(log2nc, p->channels, p->bps, c->cfg.wlen) && c->cfg.bankNum <= 64;
+    int pplog = (front_variant_exists(log2nc, 3) && !leanCand && !wideCand) ? 3 : 4;
+    if (tune.pplog > 0 && front_variant_exists(log2nc, tune.pplog) && !wideCand) pplog = tune.pplog;
     p->pplog = pplog;
     const int teams = front_teams(log2nc, pplog);
     const int groups = front_groups(log2nc, pplog) / teams; // frames in flight per team
@@ -609,6 +614,36 @@ static int choose_tile(MFCCPlan *p)
     p->featElems = (int)((((size_t)bestFt * c->vSize + 3) & ~(size_t)3) + 4);
     // Lean instantiation: mono 16-bit input, one row, even frame shift, none of the per-frame extras.
     p->mode = (leanCand && (pplog == 3 || pplog == 4) && bestTab) ? (p->melSteps > 0 ? 2 : 1) : 0;
+    p->leanChunk = tune.leanChunk;
+    p->wide1024 = false;
+    if (wideCand) {
+        // a wave's LDS region: the frame's raw bytes, one work area, the frame's log-mel rows
+        const int rawEl = wide1024_raw_bytes(c->cfg.wlen) / 4;
+        const int workEl = (zPitch + 3) & ~3;
+        const int fbkL = c->cfg.fbankFlag ? 0 : ((V * P + 3) & ~3);
+        const int teamL = rawEl + workEl + fbkL + 4; // (+ the one point the split reads past the work area)
+        size_t bytes = (size_t)wide1024_waves() * teamL * sizeof(float);
+        if (bytes > kLds) return choose_tile(p, false);
+        // the cepstral table shares the LDS when there is room (rows of P + 1 elements)
+        const size_t dctL = c->cfg.fbankFlag ? 0 : (((size_t)(c->M + c->c0) * (P + 1) + 3) & ~(size_t)3);
+        const bool dctLds = dctL > 0 && bytes + dctL * sizeof(float) <= kLds;
+        if (dctLds) bytes += dctL * sizeof(float);
+        p->wide1024 = true;
+        p->framesPerTile = 1;
+        p->rowPitch = rawEl;
+        p->rawOrZElems = workEl;
+        p->fbkElems = fbkL;
+        p->featElems = 0;
+        p->teamElems = teamL;
+        p->tabElems = dctLds ? (int)dctL : 0;
+        p->activeTeams = wide1024_waves();
+        p->ldsBytes = bytes;
+        p->blocksPerCu = 1;
+        p->mode = 0;
+        if (tune.debug)
+            fprintf(stderr, "mfcc plan: 1024-point stereo kernel, %d waves per workgroup, LDS %zu B\n", wide1024_waves(), bytes);
+        return MFCC_OK;
+    }
     // The pipelined kernel for 256 complex points (lean256.hip): a wave is a team and a tile one
     // round of 4 frames; the shared part of the LDS holds the cepstral table, the mel weights and
     // the window pairs; a wave's region holds its sample row and four work areas.  12 waves per
@@ -631,7 +666,6 @@ static int choose_tile(MFCCPlan *p)
             if (bytes > kLds) continue;
             p->lean256 = true;
             p->leanWaves = waves;
-            p->leanChunk = tune.leanChunk;
             p->framesPerTile = ft;
             p->rowPitch = rowPitchL;
             p->rowTail = 0;
@@ -699,12 +733,12 @@ static int finish_plan(MFCCPlan *p)
             const uint64_t off = (uint64_t)(d.byteOff + first0 * bpi);
             if (off > kTileOffMask) return set_error("PCM buffer larger than 2^48 bytes"), MFCC_E_ARG;
             TileDesc td;
-            if (p->lean256) {
-                // k_lean256's form: offset of the first sample itself; bit 60: it starts the signal;
+            if (p->lean256 || p->wide1024) {
+                // k_lean256's / k_wide1024's form: offset of the first sample itself; bit 60: it starts the signal;
                 // bit 61: a 16-byte vector of the fetch (which begins one sample earlier) would
                 // leave the planned bytes
                 const int64_t src = d.byteOff + first * bpi;
-                const int64_t vecs = ((int64_t)(nf - 1) * c->cfg.inc + c->cfg.wlen + 1 + 7) / 8;
+                const int64_t vecs = (((int64_t)(nf - 1) * c->cfg.inc + c->cfg.wlen + 1) * bpi + 15) / 16;
                 const bool edge = src - bpi < 0 || src - bpi + vecs * 16 > planEnd;
                 if ((uint64_t)src > kTileOffMask) return set_error("PCM buffer larger than 2^48 bytes"), MFCC_E_ARG;
                 td.src = (uint64_t)src | ((uint64_t)nf << 48) | ((uint64_t)(first > 0 ? 0 : 1) << 60) | ((uint64_t)(edge ? 1 : 0) << 61);
@@ -756,15 +790,58 @@ static int finish_plan(MFCCPlan *p)
         const int rc2 = upload_tab(c->cfg.precision, p->stageTw, &p->dStageTw);
         if (rc2) return rc2;
     }
+    if (p->wide1024) {
+        // k_wide1024's mel sums: every segment (the bins whose lower channel is s, s = 0 .. P) is cut
+        // into at most 8 parts of at most partBins (>= 16) bins; part i goes to lane i % 64 in round
+        // i / 64 (two rounds hold any filterbank: at most P + 1 + 1024 / 16 parts).  Table: 128 x {first bin, end bin, part
+        // or -1, 0}, then per channel {first part, parts} of the segment whose upper shares it takes
+        // (segment ch) and of the one whose lower shares it takes (segment ch + 1).
+        const int S1 = c->cfg.bankNum + 1, nc = c->tab.nc;
+        std::vector<int> segB(S1, 0), segE(S1, 0), partBegin(S1 + 1, 0);
+        for (int k = 0; k < nc; ++k) {
+            const int ch = c->tab.loChan[k];
+            if (ch < 0 || ch >= S1) continue;
+            if (segE[ch] == 0) segB[ch] = k;
+            segE[ch] = k + 1;
+        }
+        p->laneSeg.assign((size_t)(128 + 64) * 4, 0);
+        for (int i = 0; i < 128; ++i) p->laneSeg[4 * i + 2] = -1;
+        // bins per part: 16, or more (in steps of 8) when the longest segment would need more than 8 parts
+        int longest = 0;
+        for (int sIdx = 0; sIdx < S1; ++sIdx) longest = std::max(longest, segE[sIdx] - segB[sIdx]);
+        const int partBins = std::max(16, ((longest + 7) / 8 + 7) / 8 * 8);
+        p->melPieces = partBins / 8;
+        int parts = 0;
+        for (int sIdx = 0; sIdx < S1; ++sIdx) {
+            const int len = segE[sIdx] - segB[sIdx], n = std::max(1, (len + partBins - 1) / partBins);
+            partBegin[sIdx] = parts;
+            for (int j = 0; j < n; ++j, ++parts) {
+                if (parts >= 128) return set_error("internal: more than 128 mel segment parts"), MFCC_E_CONFIG;
+                p->laneSeg[4 * parts + 0] = segB[sIdx] + (int)((long)len * j / n);
+                p->laneSeg[4 * parts + 1] = segB[sIdx] + (int)((long)len * (j + 1) / n);
+                p->laneSeg[4 * parts + 2] = parts;
+            }
+        }
+        partBegin[S1] = parts;
+        if (c->cfg.bankNum > 64) return set_error("internal: more than 64 channels in the 1024-point stereo kernel"), MFCC_E_CONFIG;
+        for (int ch = 0; ch < c->cfg.bankNum; ++ch) {
+            int32_t *e = &p->laneSeg[(size_t)(128 + ch) * 4];
+            e[0] = partBegin[ch], e[1] = partBegin[ch + 1] - partBegin[ch];
+            e[2] = partBegin[ch + 1], e[3] = partBegin[ch + 2] - partBegin[ch + 1];
+        }
+        p->maxSeg = (parts + 63) / 64;
+    }
     HIP_TRY(hipMalloc((void **)&p->dLaneSeg, std::max<size_t>(p->laneSeg.size(), 4) * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p->dLaneSeg, p->laneSeg.data(), p->laneSeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (p->lean256 || p->wide1024) {
+        HIP_TRY(hipMalloc((void **)&p->dWork, 2 * sizeof(unsigned)));
+        HIP_TRY(hipMemset(p->dWork, 0, 2 * sizeof(unsigned)));
+    }
     if (p->mode == 2) {
         HIP_TRY(hipMalloc((void **)&p->dMelW, p->melW.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(p->dMelW, p->melW.data(), p->melW.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&p->dMelMeta, p->melMeta.size() * sizeof(int32_t)));
         HIP_TRY(hipMemcpy(p->dMelMeta, p->melMeta.data(), p->melMeta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void **)&p->dWork, 2 * sizeof(unsigned)));
-        HIP_TRY(hipMemset(p->dWork, 0, 2 * sizeof(unsigned)));
     }
     // Whole-utterance finishing pass: batch plans whose longest utterance's static rows fit the
     // LDS budget (two workgroups per CU) beside the sub-tile buffers.
@@ -1101,6 +1178,21 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     const int teams = p->activeTeams;
     const int blocks = (int)std::min<int64_t>((p->numTiles + teams - 1) / teams, (int64_t)p->numCus * p->blocksPerCu);
     if constexpr (sizeof(T) == 4) {
+        if (p->wide1024) {
+            const int waves = p->activeTeams;
+            const int64_t teamsMax = (int64_t)p->numCus * waves;
+            int chunk = p->numTiles <= teamsMax ? 1 : (int)std::max<int64_t>(2, std::min<int64_t>(32, p->numTiles / (8 * teamsMax)));
+            if (p->leanChunk > 0) chunk = p->leanChunk;
+            const int64_t chunks = (p->numTiles + chunk - 1) / chunk;
+            const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((chunks + waves - 1) / waves, p->numCus));
+            a.numUtts = p->numUtts;
+            a.planEnd = p->planEnd;
+            a.tilesPerTeam = chunk;
+            a.work = p->dWork;
+            const int rcw = launch_wide1024(a, nb, p->ldsBytes, stream);
+            if (rcw) return set_error("static-feature kernel launch failed (HIP error %d)", rcw), MFCC_E_DEVICE;
+            return MFCC_OK;
+        }
         if (p->lean256) {
             // waves draw chunks of consecutive tiles: 32 tiles when there is plenty of work (measured
             // on 2.5 M tiles: 16..96 tiles 3.34 ms, 8 tiles 3.74, 128 tiles 3.51, fixed ranges 3.7),

@@ -152,6 +152,11 @@ int lean256_nz(int wlen);                 // first-stage inputs per lane that ca
 int lean256_waves(int wlen, bool fits12); // waves (teams) per workgroup
 int lean256_mel_steps(int melSteps);      // rows of the mel weight table the kernel keeps in LDS
 int launch_lean256(const FrontArgs<float> &a, int numBlocks, size_t ldsBytes, int waves, void *stream);
+// wide1024.hip: 24-bit stereo, 1024 complex points, raw PCM bytes in LDS
+bool wide1024_applies(int log2nc, int channels, int bps, int wlen);
+int wide1024_waves();
+int wide1024_raw_bytes(int wlen);         // LDS bytes a wave reserves for a frame's raw PCM
+int launch_wide1024(const FrontArgs<float> &a, int numBlocks, size_t ldsBytes, void *stream);
 bool front_variant_exists(int log2nc, int pplog); // pplog: log2 of complex points per lane (4, 3, 2)
 int front_groups(int log2nc, int pplog);          // frames in flight per workgroup
 int front_teams(int log2nc, int pplog);           // independent teams (tile streams) per workgroup

@@ -1,0 +1,720 @@
+// Static-feature kernel for the 2048-point stereo class: 24-bit stereo PCM, frames of more than
+// 1024 and at most 2048 samples (1024 complex points), any of the derived rows {L, R, mid, side},
+// log-mel filterbank or cepstra (+ C0), log energy, zero-crossing rate, brightness, sub-band
+// energies, single precision.  Same arithmetic as k_front's general path (rows main.c:198-207,
+// PreEmphasise main.c:208, zeroCrossingRate main.c:227, Ham main.c:229, Wave2FBank mfcc.c:125-177,
+// brightness / sub-bands main.c:235-236, FBank2MFCC / FBank2C0 mfcc.c:180-208, row layout
+// main.c:241-249), organised like the 256-point kernel of lean256.hip:
+//   - a wave is a team of its own: one (frame, row) at a time, 64 lanes x 16 points, three FFT
+//     stages (16 x 16 x 4) with wave-level synchronisation only; 8 waves per workgroup, one
+//     workgroup per CU;
+//   - a tile is one frame.  What a wave keeps of it in LDS is the RAW interleaved PCM bytes (6 bytes
+//     per instant for every row together) instead of one single-precision row per derived row:
+//     10.4 KB instead of 14 - 28 KB, which is what lets 8 waves share a CU.  Every (frame, row)
+//     round expands the three instants a lane needs per point pair straight from those bytes;
+//   - the next frame's bytes are requested (16-byte vectors into registers) once the FFT of the
+//     frame's last row has freed its registers and stored over the current ones at the end of
+//     that round; frames at the first or last bytes of the buffer are patched byte by byte;
+//   - waves draw chunks of consecutive frames from a shared counter (see lean256.hip).
+#include <hip/hip_runtime.h>
+
+#include "front_util.h"
+#include "stamps.h"
+#include <type_traits>
+
+namespace mfcc {
+
+namespace {
+
+constexpr int kWideLog2Nc = 10, kWideNc = 1024, kWideG = 64, kWidePpl = 16, kWideWaves = 8, kWidePfn = 11;
+constexpr int kWideBpi = 6; // bytes per instant: two channels of three bytes
+
+typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
+typedef unsigned int u4s __attribute__((ext_vector_type(4)));
+
+// One tile (frame) as the pipeline sees it: the two 64-bit words of its TileDesc (lean encoding:
+// byte offset of the frame's first instant, bit 60: it starts the signal, bit 61: a vector of its
+// fetch would leave the planned bytes; frames field 1, or 0 for "no tile").
+struct WideTile {
+    unsigned w0, w1;
+    int outRow;
+    __device__ __forceinline__ bool valid() const { return ((w1 >> 16) & 15u) != 0; }
+    __device__ __forceinline__ bool first() const { return (w1 >> 28) & 1u; }
+    __device__ __forceinline__ bool edge() const { return (w1 >> 29) & 1u; }
+    __device__ __forceinline__ long long src() const { return (long long)(((unsigned long long)(w1 & 0xffffu) << 32) | w0); }
+};
+
+__device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ WideTile wide_desc(const TileDesc *tab, int idx, bool valid)
+{
+    WideTile t = {0u, 0u, 0};
+    if (valid) {
+        typedef const __attribute__((address_space(4))) u4s *cptr;
+        const u4s d = reinterpret_cast<cptr>(reinterpret_cast<unsigned long long>(tab))[idx];
+        t.w0 = d.x;
+        t.w1 = d.y;
+        t.outRow = (int)d.z;
+    }
+    return t;
+}
+
+// lane i takes x of lane i + 1; lane 63 takes `last`
+__device__ __forceinline__ float wave_shl1f(float x, float last)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, x), 0x130,
+                                                                 0xf, 0xf, false));
+}
+
+// 24-bit little-endian sample at byte O of the lane's window of NW dwords
+template <int O, int NW>
+__device__ __forceinline__ int sample24(const unsigned (&d)[NW])
+{
+    return window_sample<3, O, NW>(d);
+}
+
+
+// The lane's sample pairs (2n, 2n+1), n = l + 64 r, of derived row ROW (0 L, 1 R, 2 mid = 0.5 (L+R),
+// 3 side = L - R; main.c:198-207) from the frame's raw bytes: instants 2n-1 (the predecessor), 2n,
+// 2n+1 of both channels are 18 bytes from byte 12 n on.  Pre-emphasis over the whole signal
+// (PreEmphasise main.c:208, first-sample rule for the signal's first sample), Hamming window
+// (main.c:229); with ZC the zero crossings of the un-windowed samples (main.c:227), the samples
+// being formed in double with separately rounded product and difference as the reference's code
+// does, so that the sign of a near-cancelling sample is the reference's.
+template <int NZ, bool ZC, int ROW>
+__device__ __forceinline__ void wide_expand(cpx<float> (&v)[kWidePpl], int &zc, const unsigned *raw, int l,
+                                            const cpx<float> (&wreg)[NZ], double preK, float kf, bool firstTile, int wlen)
+{
+    constexpr int G = kWideG;
+    float nextFirst0 = 0; // sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r)
+    // All reads first (the first 12 of the 18 bytes; the other 6 are the next lane's first 6 and
+    // come by lane shift, for lane 63 from lane 0's next pair), then the arithmetic.
+    unsigned own[NZ][3];
+#pragma unroll
+    for (int r = 0; r < NZ; ++r) {
+        const unsigned *src = raw + 3 * (l + G * r);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) own[r][i] = src[i];
+    }
+    unsigned top0 = raw[3 * G * NZ], top1 = raw[3 * G * NZ + 1]; // (past the frame when wlen < 128 NZ: unused then)
+#pragma unroll
+    for (int r = NZ - 1; r >= 0; --r) {
+        unsigned d[5];
+        d[0] = own[r][0], d[1] = own[r][1], d[2] = own[r][2];
+        d[3] = (unsigned)__builtin_amdgcn_update_dpp((int)top0, (int)own[r][0], 0x130, 0xf, 0xf, false);
+        d[4] = (unsigned)__builtin_amdgcn_update_dpp((int)top1, (int)own[r][1], 0x130, 0xf, 0xf, false);
+        top0 = (unsigned)sgpr((int)own[r][0]);
+        top1 = (unsigned)sgpr((int)own[r][1]);
+        int c[3];
+        if constexpr (ROW == 0) {
+            c[0] = sample24<0, 5>(d), c[1] = sample24<6, 5>(d), c[2] = sample24<12, 5>(d);
+        } else if constexpr (ROW == 1) {
+            c[0] = sample24<3, 5>(d), c[1] = sample24<9, 5>(d), c[2] = sample24<15, 5>(d);
+        } else if constexpr (ROW == 2) { // L + R, halved below (the integer sum is exact)
+            c[0] = sample24<0, 5>(d) + sample24<3, 5>(d), c[1] = sample24<6, 5>(d) + sample24<9, 5>(d);
+            c[2] = sample24<12, 5>(d) + sample24<15, 5>(d);
+        } else {
+            c[0] = sample24<0, 5>(d) - sample24<3, 5>(d), c[1] = sample24<6, 5>(d) - sample24<9, 5>(d);
+            c[2] = sample24<12, 5>(d) - sample24<15, 5>(d);
+        }
+        float y1, y2;
+        if constexpr (ZC) {
+            double x[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x[i] = ROW == 2 ? 0.5 * (double)c[i] : (double)c[i];
+            y1 = (float)sub_mul_exact(x[1], x[0], preK);
+            y2 = (float)sub_mul_exact(x[2], x[1], preK);
+            if (firstTile && l == 0 && r == 0) y1 = (float)(x[1] * (1.0 - preK)); // s[1] *= 1 - k
+            // sample 2n+2 is the first sample of the next lane's pair (lane 63: of lane 0's next pair)
+            const int s0 = 2 * (l + G * r);
+            const float x2 = wave_shl1f(y1, nextFirst0);
+            const bool c01 = (y1 < 0 && y2 > 0) || (y1 > 0 && y2 < 0);
+            const bool c12 = (y2 < 0 && x2 > 0) || (y2 > 0 && x2 < 0);
+            zc += (c01 && s0 + 1 < wlen) ? 1 : 0; // pairs inside the frame only
+            zc += (c12 && s0 + 2 < wlen) ? 1 : 0;
+            nextFirst0 = __builtin_bit_cast(float, sgpr(__builtin_bit_cast(int, y1)));
+        } else {
+            float x[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x[i] = ROW == 2 ? 0.5f * (float)c[i] : (float)c[i];
+            y1 = x[1] - kf * x[0];
+            y2 = x[2] - kf * x[1];
+            if (firstTile && l == 0 && r == 0) y1 = (float)((double)x[1] * (1.0 - preK));
+        }
+        v[r] = cpx<float>{y1, y2} * wreg[r];
+    }
+#pragma unroll
+    for (int r = NZ; r < kWidePpl; ++r) v[r] = cpx<float>{0.0f, 0.0f};
+}
+
+// 1024-point complex FFT of the lane's 16 points v[r] = z[l + 64 r] into the work area Z (natural
+// order, padded): Stockham stages of radix 16, 16 and 4 as fft_stages makes them; twB / twC: the
+// lane's twiddle factors of the second and third stage.
+__device__ __forceinline__ void wide_fft(cpx<float> (&v)[kWidePpl], cpx<float> *Z, int l, const cpx<float> (&twB)[15],
+                                         const cpx<float> (&twC)[12])
+{
+    typedef float T;
+    constexpr int G = kWideG;
+    Radix<T, 16>::run(v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Z[zpad(16 * l + r)] = v[r];
+    group_sync<G>();
+    lds_read_strided<16, (64 + 4) * 8>(v, &Z[zpad(l)]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], twB[r - 1]);
+    group_sync<G>(); // every read of Z is done before any lane overwrites it
+    Radix<T, 16>::run(v);
+    {
+        const int o = ((l >> 4) << 8) + (l & 15);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Z[zpad(o + r * 16)] = v[r];
+    }
+    group_sync<G>();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) lds_read_strided<4, (256 + 16) * 8>(&v[4 * b], &Z[zpad(l + 64 * b)]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 1; r < 4; ++r) v[4 * b + r] = cmul(v[4 * b + r], twC[b * 3 + r - 1]);
+    group_sync<G>();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Radix<T, 4>::run(&v[4 * b]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Z[zpad(l + 64 * b + r * 256)] = v[4 * b + r];
+    group_sync<G>();
+}
+
+// Sub-band sums straight from the lane's registers when a band is a whole number of 64-bin strides
+// (S = 2, 4, 8, 16): bin l + 64 q lies in band q / W and bin 1024 - l - 64 q in band (15 - q) / W for
+// l >= 1, W = 16 / S; lane 0 holds bins 64 q and 1024 - 64 q (512 for q = 0).  e[b] = sum of the
+// band's powers, ek[b] = sum of (bin + 1) x power, over the lane's 16 bins.
+template <int S>
+__device__ __forceinline__ void wide_bands(const float (&pa)[8], const float (&pb)[8], int l, float (&e)[16], float (&ek)[16])
+{
+    constexpr int W = 16 / S, NC = kWideNc, G = kWideG;
+#pragma unroll
+    for (int b = 0; b < S; ++b) e[b] = 0.0f, ek[b] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = l + G * q;
+        const int k2 = k == 0 ? NC / 2 : NC - k;
+        e[q / W] += pa[q];
+        ek[q / W] += (float)(k + 1) * pa[q];
+        // (lane 0's second bin sits one band higher than the other lanes' whenever 64 q starts a band)
+        const int bHi = (15 - q) / W, bLane0 = q == 0 ? (S / 2) : (16 - q) / W;
+        const float p2 = pb[q], w2 = (float)(k2 + 1) * pb[q];
+        if (bHi == bLane0) {
+            e[bHi] += p2;
+            ek[bHi] += w2;
+        } else {
+            e[bHi] += l == 0 ? 0.0f : p2;
+            ek[bHi] += l == 0 ? 0.0f : w2;
+            e[bLane0 < S ? bLane0 : S - 1] += l == 0 ? p2 : 0.0f;
+            ek[bLane0 < S ? bLane0 : S - 1] += l == 0 ? w2 : 0.0f;
+        }
+    }
+}
+
+} // namespace
+
+// NZ: first-stage inputs of a lane that can be non-zero, ceil(wlen / 128).  ZC: zero-crossing rate
+// on; the samples are then formed in double with separately rounded product and difference, as
+// the reference's code does, so that the sign of a near-cancelling sample is the reference's.
+template <int NZ, bool ZC>
+__global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<float> a)
+{
+    constexpr int NC = kWideNc, G = kWideG, PPL = kWidePpl, NPAIR = PPL / 2, TEAM = 64, WAVES = kWideWaves;
+    constexpr int PFN = kWidePfn, BPI = kWideBpi;
+    typedef float T;
+    STAMP_DECL
+    STAMP_START;
+    const int tid = threadIdx.x;
+    const int wave = sgpr(tid >> 6);
+    const int tt0 = tid & 63;
+    int tt = tt0, l = tt0;
+
+    // LDS, one region per wave: [raw PCM bytes of the frame | work area | log-mel rows of the frame]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (in front of them, when there is room: the cepstral table with rows of P + 1 elements)
+    T *dctL = reinterpret_cast<T *>(smem);
+    unsigned char *region = smem + ((size_t)a.tabElems + (size_t)wave * a.teamElems) * sizeof(T);
+    unsigned *raw = reinterpret_cast<unsigned *>(region);
+    T *Zt = reinterpret_cast<T *>(region) + a.rowPitch; // (rowPitch: elements reserved for the raw bytes)
+    cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
+    cpx<T> *AB = Z;                                               // per bin (loWt p, p - loWt p)
+    T *bandE = Zt + 2 * NC;                                       // sub-band sums (general band widths)
+    T *Pw = Zt;                                                   // plain power values, before AB
+    T *fbkSep = Zt + a.rawOrZElems;                               // V x P log-mel values (cepstral mode)
+
+    if (a.tabElems > 0) {
+        const int rows = a.M + a.c0Flag, pitch = a.P + 1;
+        for (int i = tid; i < rows * pitch; i += WAVES * 64) {
+            const int j = i / pitch, k = i - j * pitch;
+            dctL[i] = k < a.P ? a.dctT[j * a.dctPitch + k] : (T)0;
+        }
+        __syncthreads();
+    }
+    const T *dctTab = a.tabElems > 0 ? dctL : a.dctT;
+    const int dctPitch = a.tabElems > 0 ? a.P + 1 : a.dctPitch;
+    // Per-lane constants.  The window pairs stay in registers for the whole launch.  The twiddle
+    // factors of the second and third FFT stage and the split factors are read (through L1, the
+    // same few KB for every wave) before the round's first FFT stage, the filterbank weights after
+    // the split: each well before its use and before the round's result stores, so that waiting for
+    // a table never means waiting for stores issued just ahead of it.
+    cpx<T> wreg[NZ];
+#pragma unroll
+    for (int r = 0; r < NZ; ++r) wreg[r] = reinterpret_cast<const cpx<T> *>(a.window)[l + G * r];
+    const cpx<T> *twt = reinterpret_cast<const cpx<T> *>(a.tw), *splitTab = reinterpret_cast<const cpx<T> *>(a.splitTw);
+    // mel segment parts of the lane (round 0 and 1) and the part ranges of the lane's channel
+    const int4 *lseg = reinterpret_cast<const int4 *>(a.laneSeg);
+    const int4 part0 = lseg[l], part1 = lseg[64 + l], chanParts = lseg[128 + l];
+    const float kf = (float)a.preK;
+    const int JW = a.M + a.c0Flag;
+    const int F_V = a.V, F_S = a.S;
+
+    // The wave's stream of tiles (chunks drawn from a.work, see lean256.hip).
+    const int teamId = blockIdx.x * WAVES + wave, numTeams = gridDim.x * WAVES, C = a.tilesPerTeam;
+    int chunkBase = teamId * C, chunkPos = 0, nextBase = 0;
+    bool haveNext = false, needDraw = true;
+    auto draw = [&]() {
+        unsigned drawn = 0;
+        if (tt == 0) drawn = atomicAdd(a.work, 1u);
+        nextBase = (sgpr((int)drawn) + numTeams) * C;
+        haveNext = true;
+        needDraw = false;
+    };
+    auto next_tile = [&]() {
+        if (chunkPos == C) {
+            if (!haveNext) {
+                if (!needDraw) return -1;
+                draw();
+            }
+            chunkBase = nextBase;
+            chunkPos = 0;
+            haveNext = false;
+            needDraw = chunkBase < a.numTiles;
+        }
+        const int id = chunkBase + chunkPos;
+        if (id >= a.numTiles) return -1;
+        ++chunkPos;
+        return id;
+    };
+    auto draw_step = [&]() {
+        if (needDraw && !haveNext) draw();
+    };
+    auto next_tile_s = [&]() {
+        const int id = sgpr(next_tile());
+        chunkBase = sgpr(chunkBase);
+        chunkPos = sgpr(chunkPos);
+        nextBase = sgpr(nextBase);
+        return id;
+    };
+    auto finish = [&]() {
+        __threadfence();
+        if (tt == 0 && atomicInc(a.work + 1, (unsigned)numTeams - 1u) == (unsigned)numTeams - 1u) {
+            __hip_atomic_store(a.work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (chunkBase >= a.numTiles) {
+        finish();
+        STAMP_FLUSH;
+        return;
+    }
+    const TileDesc *tab = a.tiles;
+    int id = next_tile_s();
+    WideTile cur = wide_desc(tab, id, true);
+    id = next_tile_s();
+    WideTile nx = wide_desc(tab, id < 0 ? 0 : id, id >= 0);
+    id = next_tile_s();
+    WideTile nn = wide_desc(tab, id < 0 ? 0 : id, id >= 0);
+
+    const int tileBytes = (a.wlen + 1) * BPI;      // the frame's instants and the predecessor of the first
+    const int nvec = (tileBytes + 15) >> 4;
+    // Requests the raw bytes of tile t (vector j of lane tt = bytes 16 (tt + 64 j) .. + 15, byte 0
+    // being the first byte of the predecessor of the frame's first instant).  Tiles at the first or
+    // last bytes of the buffer keep every vector inside it by clamping its offset (store_raw then
+    // redoes such a tile byte by byte).
+    // (every vector is loaded, the ones behind the tile's last from the last one's place: the
+    // registers then have a single definition and are dead once stored)
+    auto fetch = [&](const WideTile &t, u4u (&pf)[PFN]) {
+        const long long off0 = t.src() - BPI;
+        int lo = 0, hi = 16 * (nvec - 1);
+        if (t.edge()) {
+            lo = (int)(off0 < 0 ? -off0 : 0);
+            hi = (int)min(a.planEnd - 16 - off0, (long long)hi);
+        }
+        const unsigned char *g = a.pcm + off0;
+#pragma unroll
+        for (int j = 0; j < PFN; ++j) pf[j] = *reinterpret_cast<const u4u *>(g + min(max(16 * (tt + j * TEAM), lo), hi));
+    };
+    auto store_raw = [&](const WideTile &t, const u4u (&pf)[PFN]) {
+#pragma unroll
+        for (int j = 0; j < PFN; ++j) {
+            const int vj = tt + j * TEAM;
+            if (vj < nvec) reinterpret_cast<uint4 *>(raw)[vj] = make_uint4(pf[j].x, pf[j].y, pf[j].z, pf[j].w);
+        }
+        if (t.edge()) {
+            const long long off0 = t.src() - BPI;
+            unsigned char *rb = reinterpret_cast<unsigned char *>(raw);
+            for (int b = tt; b < tileBytes; b += TEAM) {
+                const long long g = off0 + b;
+                rb[b] = (g >= 0 && g < a.planEnd) ? a.pcm[g] : (unsigned char)0;
+            }
+        }
+    };
+
+    // Prologue: the first tile's bytes.
+    {
+        u4u pf0[PFN];
+        fetch(cur, pf0);
+        store_raw(cur, pf0);
+        team_sync<TEAM>();
+    }
+
+    // One (frame, row) round.  The frame's last row (LAST) asks for the next frame's bytes once its
+    // spectrum is in registers and stores them over this frame's before its own results go out, so
+    // that the registers carrying them are live inside that round only and the wait for them does
+    // not include the round's result stores.
+    WideTile d3 = {0u, 0u, 0};
+    auto round = [&](const int vv, auto lastTag) {
+        constexpr bool LAST = decltype(lastTag)::value;
+        u4u pf[LAST ? PFN : 1];
+        // (the lane index is made opaque once per round: what derives from it -- addresses, bin
+        // weights, masks -- is then recomputed here in a few instructions instead of being kept in
+        // registers, or spilled, across the whole loop)
+        asm volatile("" : "+v"(tt));
+        l = tt;
+        float *outRow = a.out + (long long)cur.outRow * a.step;
+        const bool firstTile = cur.first();
+        {
+            STAMP(0);
+            float *fo = outRow + vv * a.D;
+            // ---- the lane's sample pairs (2n, 2n+1), n = l + 64 r, of derived row vv from the raw
+            //      bytes: instants 2n-1 (predecessor), 2n, 2n+1 of both channels are 18 bytes from
+            //      byte 12 n on; rows main.c:198-207, PreEmphasise main.c:208 (first-sample rule for
+            //      the signal's first sample), Ham main.c:229, te mfcc.c:138-142
+            cpx<T> v[PPL];
+            int zc = 0;
+            switch (vv) { // (the same for every lane)
+            case 0: wide_expand<NZ, ZC, 0>(v, zc, raw, l, wreg, a.preK, kf, firstTile, a.wlen); break;
+            case 1: wide_expand<NZ, ZC, 1>(v, zc, raw, l, wreg, a.preK, kf, firstTile, a.wlen); break;
+            case 2: wide_expand<NZ, ZC, 2>(v, zc, raw, l, wreg, a.preK, kf, firstTile, a.wlen); break;
+            default: wide_expand<NZ, ZC, 3>(v, zc, raw, l, wreg, a.preK, kf, firstTile, a.wlen); break;
+            }
+            T te = 0;
+            if (a.energyFlag) {
+                cpx<T> e2 = {0, 0};
+#pragma unroll
+                for (int r = 0; r < NZ; ++r) e2 += v[r] * v[r];
+                te = group_sum<T, G>((T)4 * (e2.x + e2.y), nullptr, tt); // (half-scaled window)
+            }
+            if constexpr (ZC) zc = group_sum<int, G>(zc, nullptr, tt);
+            STAMP(1);
+            cpx<T> twB[15], twC[12], swreg[NPAIR];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) twB[r - 1] = twt[(r - 1) * 16 + (l & 15)]; // sub-transform size 16: [r-1][l mod 16]
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 1; r < 4; ++r) twC[b * 3 + r - 1] = twt[15 * 16 + (r - 1) * 256 + 64 * b + l]; // size 256: [r-1][l + 64 b]
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) swreg[q] = splitTab[G * q + l];
+            STAMP(2);
+
+            // ---- 1024-point complex FFT of z[n] = x[2n] + i x[2n+1] (Realft mfcc.c:262-270)
+            wide_fft(v, Z, l, twB, twC);
+            STAMP(3);
+
+            // ---- real-FFT split and power (mfcc.c:274-290, ek of mfcc.c:153-155)
+            T pa[NPAIR], pb[NPAIR];
+            {
+                constexpr int QS = (G + G / 16) * 8;
+                cpx<T> zas[NPAIR], rev[NPAIR];
+                lds_read_strided<NPAIR, QS>(zas, &Z[zpad(l)]);
+                lds_read_strided<NPAIR, QS>(rev, &Z[zpad(NC - l - G * (NPAIR - 1))]); // (lane 0: one point past the area, unused)
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) split_power<T>(zas[q], rev[NPAIR - 1 - q], swreg[q], pa[q], pb[q]);
+                // bin 0 packs Re + Im of Z[0] (mfcc.c:288-290); bin nc/2 is |Z[nc/2]|^2
+                const cpx<T> z0 = Z[0], zh = Z[zpad(NC / 2)];
+                const T p0 = (T)4 * (z0.x + z0.y) * (z0.x + z0.y);
+                const T ph = (T)4 * (zh.x * zh.x + zh.y * zh.y);
+                pa[0] = l == 0 ? p0 : pa[0];
+                pb[0] = l == 0 ? ph : pb[0];
+            }
+            // brightness without sub-bands: power-weighted mean bin index straight from registers
+            T regTotal = 0, regNum = 0;
+            if (a.brightFlag && F_S == 0) {
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) {
+                    const int k = l + G * q;
+                    const int k2 = k == 0 ? NC / 2 : NC - k;
+                    regTotal += pa[q] + pb[q];
+                    regNum += (T)(k + 1) * pa[q] + (T)(k2 + 1) * pb[q];
+                }
+                regTotal = group_sum<T, G>(regTotal, nullptr, tt);
+                regNum = group_sum<T, G>(regNum, nullptr, tt);
+            }
+            group_sync<G>(); // every lane has read its Z points: the work area can be reused
+            T lwreg[2 * NPAIR]; // weights of bins l + 64 q and nc - l - 64 q (lane 0, q = 0: bin nc / 2)
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) {
+                lwreg[2 * q] = a.loWt[G * q + l];
+                lwreg[2 * q + 1] = a.loWt[(q == 0 && l == 0) ? NC / 2 : NC - G * q - l];
+            }
+            STAMP(4);
+
+            // ---- sub-band energies / brightness (main.c:235-236): from the registers when a band is a
+            //      whole number of 64-bin strides, else from the plain power values in the work area
+            const bool bandsFromRegs = F_S == 2 || F_S == 4 || F_S == 8 || F_S == 16;
+            if (bandsFromRegs) {
+                float e[16], ek[16];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) e[g] = 0.0f, ek[g] = 0.0f;
+                if (F_S == 8) wide_bands<8>(pa, pb, l, e, ek);
+                else if (F_S == 4) wide_bands<4>(pa, pb, l, e, ek);
+                else if (F_S == 2) wide_bands<2>(pa, pb, l, e, ek);
+                else wide_bands<16>(pa, pb, l, e, ek);
+                // the 64 lanes' partial sums through the (free) work area: [value i][lane], then lane
+                // (i, j) = (l % 16, l / 16) adds the 16 lanes 16 j .. 16 j + 15 of value i, and the four
+                // quarters are added by lane exchange: lane i < 16 ends with the total of e[i], lanes
+                // 16 + i with it too (ek likewise in a second pass)
+                T tot[2];
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) Pw[g * 64 + l] = pass == 0 ? e[g] : ek[g];
+                    group_sync<G>();
+                    const float4 *q4 = reinterpret_cast<const float4 *>(Pw + (l & 15) * 64 + (l >> 4) * 16);
+                    const float4 s0 = q4[0], s1 = q4[1], s2 = q4[2], s3 = q4[3];
+                    T sum = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+                            (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+                    sum += __shfl_xor(sum, 16, 64);
+                    sum += __shfl_xor(sum, 32, 64);
+                    tot[pass] = sum;
+                    group_sync<G>();
+                }
+                // total power and its bin-weighted sum: over the bands, i.e. over lanes 0 .. S-1 of a row
+                const T eb = (l & 15) < F_S ? tot[0] : (T)0, ekb = (l & 15) < F_S ? tot[1] : (T)0;
+                const T total = group_sum<T, 16>(eb, nullptr, tt), num = group_sum<T, 16>(ekb, nullptr, tt);
+                const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
+                if (l < F_S) fo[subAt + l] = tot[0] / total;
+                if (l == 0 && a.brightFlag) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / total / (T)NC;
+            } else if (F_S > 0) {
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) {
+                    const int k = l + G * q;
+                    const int k2 = k == 0 ? NC / 2 : NC - k;
+                    Pw[k] = pa[q];
+                    Pw[k2] = pb[q];
+                }
+                group_sync<G>();
+                const int nseg = F_S, width = NC / nseg;
+                const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
+                int lpb = 1;
+                while (lpb * 2 * nseg <= G && lpb < 64) lpb *= 2;
+                const int perPass = G / lpb;
+                for (int b0 = 0; b0 < nseg; b0 += perPass) {
+                    const int b = b0 + l / lpb, sl = l & (lpb - 1);
+                    T e = 0, ek = 0;
+                    if (b < nseg) {
+                        const int lo = b * width, hi = (b == nseg - 1) ? NC : lo + width;
+                        for (int k = lo + sl; k < hi; k += lpb) {
+                            const T pv = Pw[k];
+                            e += pv;
+                            ek += (T)(k + 1) * pv;
+                        }
+                    }
+                    for (int o = lpb >> 1; o > 0; o >>= 1) {
+                        e += __shfl_xor(e, o, 64);
+                        ek += __shfl_xor(ek, o, 64);
+                    }
+                    if (b < nseg && sl == 0) {
+                        bandE[b] = e;
+                        bandE[nseg + b] = ek;
+                    }
+                }
+                group_sync<G>();
+                if (l == 0) {
+                    T total = 0, num = 0;
+                    for (int g = 0; g < nseg; ++g) {
+                        total += bandE[g];
+                        num += bandE[nseg + g];
+                    }
+                    if (a.brightFlag) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / total / (T)NC;
+                    for (int g = 0; g < nseg; ++g) fo[subAt + g] = bandE[g] / total;
+                }
+            }
+            if (l == 0) {
+                if (F_S == 0 && a.brightFlag) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = regNum / regTotal / (T)NC;
+                if (a.energyFlag) fo[a.M + a.c0Flag] = tlog<T>(te);                               // main.c:243
+                if (ZC) fo[a.M + a.c0Flag + a.energyFlag] = (T)zc / (T)(a.wlen - 1);              // main.c:244
+            }
+
+            STAMP(7);
+            if constexpr (LAST) {
+                if (nx.valid()) {
+                    draw_step();
+                    fetch(nx, pf);
+                }
+            }
+            // ---- per bin, exactly the two products of mfcc.c:160-162: t1 = loWt ek and ek - t1
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) {
+                const int k = l + G * q;
+                const int k2 = k == 0 ? NC / 2 : NC - k;
+                const T t1 = lwreg[2 * q] * pa[q];
+                const T t2 = lwreg[2 * q + 1] * pb[q];
+                AB[k] = {t1, pa[q] - t1};
+                AB[k2] = {t2, pb[q] - t2};
+            }
+            group_sync<G>();
+            STAMP(5);
+            // ---- mel filterbank (mfcc.c:152-163): the bins whose lower channel is c form one
+            //      segment, cut by the host into parts of at most 16 bins; a lane sums T = sum t1 and
+            //      U = sum (ek - t1) of its part (one per round, two rounds) in bin order, the part sums
+            //      go to the work area, and the lane of channel b adds the parts of U[b-1] and of T[b]
+            //      in part (= bin) order; then log(max(., 1)) (mfcc.c:171-176)
+            cpx<T> ps[2];
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int4 sg = rd == 0 ? part0 : part1;
+                cpx<T> acc = {0, 0};
+                if (rd < a.maxSeg) {
+                    for (int h = 0; h < a.melPieces; ++h) { // melPieces x 8 bins per part at most (reads past the part stay inside the work area and are dropped)
+                        cpx<T> vq[8];
+                        lds_read_strided<8, 8>(vq, &AB[sg.x + 8 * h]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (sg.x + 8 * h + i < sg.y) acc = cadd(acc, vq[i]);
+                    }
+                }
+                ps[rd] = acc;
+            }
+            STAMP(8);
+            group_sync<G>(); // every part has been read: the pairs' place takes the part sums
+            if (part0.z >= 0) {
+                Pw[part0.z] = ps[0].x;
+                Pw[128 + part0.z] = ps[0].y;
+            }
+            if (a.maxSeg > 1 && part1.z >= 0) {
+                Pw[part1.z] = ps[1].x;
+                Pw[128 + part1.z] = ps[1].y;
+            }
+            group_sync<G>();
+            T lv = 0;
+            if (l < a.P) {
+                // (at most 8 parts per segment: all reads go out together, the sums stay in part order)
+                T pu[8], pt[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pu[j] = Pw[128 + chanParts.x + j];
+                    pt[j] = Pw[chanParts.z + j];
+                }
+                T mu = 0, mt = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    mu += j < chanParts.y ? pu[j] : (T)0;
+                    mt += j < chanParts.w ? pt[j] : (T)0;
+                }
+                const T m = mu + mt;
+                lv = tlog<T>(m < (T)1 ? (T)1 : m);
+            }
+            if constexpr (LAST) {
+                // every row of the frame has expanded its samples (the FFT's exchanges lie between):
+                // the next frame's bytes take their place
+                if (nx.valid()) store_raw(nx, pf);
+            }
+            if (l < a.P) {
+                if (a.fbankFlag) fo[l] = lv;
+                else fbkSep[vv * a.P + l] = lv;
+            }
+            team_sync<TEAM>(); // the work area is free for the next round, the raw bytes are in place
+            STAMP(6);
+        }
+        if (LAST && !a.fbankFlag) {
+            // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208) of the frame's
+            //      rows as 16 x 16 x 4 matrix-core products: lane (i, g) = (lane % 16, lane / 16) feeds
+            //      fbk[row i][k0 + g] and dct[coefficient i][k0 + g] and holds the results of rows
+            //      4 g .. 4 g + 3 for coefficient i.  The table's row M is all ones (C0).
+            const int i16 = tt & 15, g4 = tt >> 4;
+            for (int jb = 0; jb * 16 < JW; ++jb) {
+                const int jB = jb * 16 + i16;
+                const T *fa = fbkSep + (i16 < F_V ? i16 : 0) * a.P;
+                const T *db = dctTab + (jB < JW ? jB : 0) * dctPitch;
+                Acc4<T> acc = {0, 0, 0, 0};
+                T bvs[16]; // the block's table values first (read through L1), then the products
+#pragma unroll
+                for (int i = 0; i < 16; ++i) bvs[i] = (4 * i < a.P && jB < JW) ? db[4 * i + g4] : (T)0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int k = 4 * i + g4;
+                    if (4 * i < a.P) {
+                        T fv = fa[k < a.P ? k : 0];
+                        fv = (i16 < F_V && k < a.P) ? fv : (T)0;
+                        acc = mfma16(fv, bvs[i], acc);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (g4 == 0 && r < F_V && jB < JW) outRow[r * a.D + jB] = acc[r] * a.mfnorm;
+            }
+            team_sync<TEAM>();
+        }
+        STAMP(9);
+    };
+    for (;;) {
+        // the descriptor three frames ahead: asked for now, moved into place at the frame's end
+        const int id3 = next_tile_s();
+        d3 = wide_desc(tab, id3 < 0 ? 0 : id3, id3 >= 0);
+        for (int vv = 0; vv + 1 < F_V; ++vv) round(vv, std::false_type{});
+        round(F_V - 1, std::true_type{});
+        if (!nx.valid()) break;
+        cur = nx;
+        nx = nn;
+        nn = d3;
+    }
+    finish();
+    STAMP_FLUSH;
+}
+
+// Geometry the host plans with.
+int wide1024_nz(int wlen) { return (wlen + 127) / 128; }
+int wide1024_waves() { return kWideWaves; }
+int wide1024_raw_bytes(int wlen) { return ((((wlen + 1) * kWideBpi + 15) >> 4) << 4); }
+
+bool wide1024_applies(int log2nc, int channels, int bps, int wlen)
+{
+    const int vecs = ((wlen + 1) * kWideBpi + 15) >> 4;
+    return log2nc == kWideLog2Nc && channels == 2 && bps == 3 && vecs <= kWidePfn * 64 && wide1024_nz(wlen) >= 9 &&
+           wide1024_nz(wlen) <= 16;
+}
+
+template <int NZ, bool ZC>
+static int launch_wide_t(const FrontArgs<float> &a, int numBlocks, size_t lds, hipStream_t st)
+{
+    static bool attrSet[16] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 16 || !attrSet[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide1024<NZ, ZC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        if (dev < 16) attrSet[dev] = true;
+    }
+    hipLaunchKernelGGL((k_wide1024<NZ, ZC>), dim3(numBlocks), dim3(kWideWaves * 64), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+int launch_wide1024(const FrontArgs<float> &a, int numBlocks, size_t lds, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the two window lengths that matter get their own count of first-stage inputs; the rest share 16
+    const int nz = wide1024_nz(a.wlen);
+    if (nz == 14) return a.zcFlag ? launch_wide_t<14, true>(a, numBlocks, lds, st) : launch_wide_t<14, false>(a, numBlocks, lds, st);
+    return a.zcFlag ? launch_wide_t<16, true>(a, numBlocks, lds, st) : launch_wide_t<16, false>(a, numBlocks, lds, st);
+}
+
+} // namespace mfcc
