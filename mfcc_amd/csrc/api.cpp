@@ -82,7 +82,7 @@ struct MFCCPlan {
     int64_t totalRows = 0;
     int numTiles = 0, numChunks = 0;
     int framesPerTile = 0, rowPitch = 0, rawOrZElems = 0, teamElems = 0, numRegBlocks = 0;
-    int tabElems = 0, winPad = 0, featElems = 0, fbkElems = 0, rowTail = 0;
+    int tabElems = 0, tabPitch = 0, winPad = 0, featElems = 0, fbkElems = 0, rowTail = 0;
     int blocksPerCu = 1, numCus = 256, pplog = 4;
     int activeTeams = 1;
     int deltaSubRows = 0, deltaRedOffset = 0; // fused delta kernel geometry (0: not used)
@@ -619,14 +619,20 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
     if (wideCand) {
         // a wave's LDS region: the frame's raw bytes, one work area, the frame's log-mel rows
         const int rawEl = wide1024_raw_bytes(c->cfg.wlen) / 4;
-        const int workEl = (zPitch + 3) & ~3;
-        const int fbkL = c->cfg.fbankFlag ? 0 : ((V * P + 3) & ~3);
+        const int workEl = 2 * (nc + nc / 16); // the padded complex points; every later use of the area is smaller
+        const int P4 = (P + 3) & ~3;
+        const int fbkL = c->cfg.fbankFlag ? 0 : V * P4; // log-mel values [channel][row], channels padded to 4
         const int teamL = rawEl + workEl + fbkL + 4; // (+ the one point the split reads past the work area)
         size_t bytes = (size_t)wide1024_waves() * teamL * sizeof(float);
         if (bytes > kLds) return choose_tile(p, false);
-        // the cepstral table shares the LDS when there is room (rows of P + 1 elements)
-        const size_t dctL = c->cfg.fbankFlag ? 0 : (((size_t)(c->M + c->c0) * (P + 1) + 3) & ~(size_t)3);
-        const bool dctLds = dctL > 0 && bytes + dctL * sizeof(float) <= kLds;
+        // the cepstral table shares the LDS when there is room: rows zero-padded to 4 channels, odd pitch
+        size_t dctL = 0;
+        const int dctPitchL = P4 + 1;
+        if (!c->cfg.fbankFlag) {
+            const size_t el = ((size_t)(c->M + c->c0) * dctPitchL + 3) & ~(size_t)3;
+            if (bytes + el * sizeof(float) <= kLds) dctL = el;
+        }
+        const bool dctLds = dctL > 0;
         if (dctLds) bytes += dctL * sizeof(float);
         p->wide1024 = true;
         p->framesPerTile = 1;
@@ -636,6 +642,7 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
         p->featElems = 0;
         p->teamElems = teamL;
         p->tabElems = dctLds ? (int)dctL : 0;
+        p->tabPitch = dctPitchL;
         p->activeTeams = wide1024_waves();
         p->ldsBytes = bytes;
         p->blocksPerCu = 1;
@@ -792,8 +799,8 @@ static int finish_plan(MFCCPlan *p)
     }
     if (p->wide1024) {
         // k_wide1024's mel sums: every segment (the bins whose lower channel is s, s = 0 .. P) is cut
-        // into at most 8 parts of at most partBins (>= 16) bins; part i goes to lane i % 64 in round
-        // i / 64 (two rounds hold any filterbank: at most P + 1 + 1024 / 16 parts).  Table: 128 x {first bin, end bin, part
+        // into at most 10 parts of at most partBins (>= 15, odd) bins; part i goes to lane i % 64 in round
+        // i / 64 (partBins is raised until two rounds hold the filterbank).  Table: 128 x {first bin, end bin, part
         // or -1, 0}, then per channel {first part, parts} of the segment whose upper shares it takes
         // (segment ch) and of the one whose lower shares it takes (segment ch + 1).
         const int S1 = c->cfg.bankNum + 1, nc = c->tab.nc;
@@ -806,11 +813,17 @@ static int finish_plan(MFCCPlan *p)
         }
         p->laneSeg.assign((size_t)(128 + 64) * 4, 0);
         for (int i = 0; i < 128; ++i) p->laneSeg[4 * i + 2] = -1;
-        // bins per part: 16, or more (in steps of 8) when the longest segment would need more than 8 parts
+        // bins per part: an odd number (the parts of a long segment then start in different LDS
+        // banks), 15 or the next odd number with which the longest segment has at most 10 parts
         int longest = 0;
         for (int sIdx = 0; sIdx < S1; ++sIdx) longest = std::max(longest, segE[sIdx] - segB[sIdx]);
-        const int partBins = std::max(16, ((longest + 7) / 8 + 7) / 8 * 8);
-        p->melPieces = partBins / 8;
+        int partBins = 15;
+        for (;; partBins += 2) { // (ends: with 17 bins or more, 64 channels make at most 65 + 1024 / 17 parts)
+            int total = 0;
+            for (int sIdx = 0; sIdx < S1; ++sIdx) total += std::max(1, (segE[sIdx] - segB[sIdx] + partBins - 1) / partBins);
+            if ((longest + partBins - 1) / partBins <= 10 && total <= 128) break;
+        }
+        p->melPieces = (partBins + 7) / 8;
         int parts = 0;
         for (int sIdx = 0; sIdx < S1; ++sIdx) {
             const int len = segE[sIdx] - segB[sIdx], n = std::max(1, (len + partBins - 1) / partBins);
@@ -1141,6 +1154,7 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.teamElems = p->teamElems;
     a.activeTeams = p->activeTeams;
     a.tabElems = p->tabElems;
+    a.tabPitch = p->tabPitch;
     a.winPad = p->winPad;
     a.featElems = p->featElems;
     a.fbkElems = p->fbkElems;

@@ -83,6 +83,7 @@ struct FrontArgs {
     int teamElems;         // elements of one team's LDS region (rows, work areas, staging, sums)
     int activeTeams;       // teams of a workgroup that take tiles (1 .. teams per workgroup)
     int tabElems;          // elements of the LDS copy of the tables (0: tables are read through L1/L2)
+    int tabPitch;          // k_wide1024: row pitch of the cepstral table's LDS copy
     int winPad;            // elements reserved for the window inside that copy
     int featElems;         // elements of the static-feature staging area (framesPerTile x vSize, padded)
     int fbkElems;          // elements of the log-mel area, framesPerTile x V x P (0 in filterbank mode)

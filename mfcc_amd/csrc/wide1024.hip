@@ -81,12 +81,13 @@ __device__ __forceinline__ int sample24(const unsigned (&d)[NW])
 // (main.c:229); with ZC the zero crossings of the un-windowed samples (main.c:227), the samples
 // being formed in double with separately rounded product and difference as the reference's code
 // does, so that the sign of a near-cancelling sample is the reference's.
-template <int NZ, bool ZC, int ROW>
-__device__ __forceinline__ void wide_expand(cpx<float> (&v)[kWidePpl], int &zc, const unsigned *raw, int l,
-                                            const cpx<float> (&wreg)[NZ], double preK, float kf, bool firstTile, int wlen)
+template <int NZ, bool ZC, int ROW, bool EXACT>
+__device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, const unsigned *raw, int l,
+                                            const cpx<float> (&wreg)[NZ], double preK, float kf, float zcThr, bool firstTile, int wlen)
 {
     constexpr int G = kWideG;
     float nextFirst0 = 0; // sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r)
+    bool unsure = false;
     // All reads first (the first 12 of the 18 bytes; the other 6 are the next lane's first 6 and
     // come by lane shift, for lane 63 from lane 0's next pair), then the arithmetic.
     unsigned own[NZ][3];
@@ -119,17 +120,30 @@ __device__ __forceinline__ void wide_expand(cpx<float> (&v)[kWidePpl], int &zc, 
         }
         float y1, y2;
         if constexpr (ZC) {
-            double x[3];
+            // The crossings need the sign of the reference's double-precision sample x1 - rnd(k x0).
+            // The single-precision x1 - kf x0 (one rounding, inputs exact) has that sign whenever it
+            // is not tiny against x0: the two differ by (kf - k) x0 and the product's rounding, and
+            // zcThr is four times that bound.  A frame in which some sample is that close to zero
+            // is expanded again with EXACT, in double as the reference's code does it.
+            float x[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) x[i] = ROW == 2 ? 0.5 * (double)c[i] : (double)c[i];
-            y1 = (float)sub_mul_exact(x[1], x[0], preK);
-            y2 = (float)sub_mul_exact(x[2], x[1], preK);
-            if (firstTile && l == 0 && r == 0) y1 = (float)(x[1] * (1.0 - preK)); // s[1] *= 1 - k
+            for (int i = 0; i < 3; ++i) x[i] = ROW == 2 ? 0.5f * (float)c[i] : (float)c[i];
+            if constexpr (EXACT) {
+                y1 = (float)sub_mul_exact((double)x[1], (double)x[0], preK);
+                y2 = (float)sub_mul_exact((double)x[2], (double)x[1], preK);
+            } else {
+                y1 = __builtin_fmaf(-kf, x[0], x[1]);
+                y2 = __builtin_fmaf(-kf, x[1], x[2]);
+                // (strictly below: a zero sample after a zero predecessor is exact)
+                unsure |= __builtin_fabsf(y1) < zcThr * __builtin_fabsf(x[0]) || __builtin_fabsf(y2) < zcThr * __builtin_fabsf(x[1]);
+            }
+            if (firstTile && l == 0 && r == 0) y1 = (float)((double)x[1] * (1.0 - preK)); // s[1] *= 1 - k
             // sample 2n+2 is the first sample of the next lane's pair (lane 63: of lane 0's next pair)
             const int s0 = 2 * (l + G * r);
             const float x2 = wave_shl1f(y1, nextFirst0);
-            const bool c01 = (y1 < 0 && y2 > 0) || (y1 > 0 && y2 < 0);
-            const bool c12 = (y2 < 0 && x2 > 0) || (y2 > 0 && x2 < 0);
+            // (opposite signs = negative product; the samples are far from the underflow range)
+            const bool c01 = y1 * y2 < 0.0f;
+            const bool c12 = y2 * x2 < 0.0f;
             zc += (c01 && s0 + 1 < wlen) ? 1 : 0; // pairs inside the frame only
             zc += (c12 && s0 + 2 < wlen) ? 1 : 0;
             nextFirst0 = __builtin_bit_cast(float, sgpr(__builtin_bit_cast(int, y1)));
@@ -145,6 +159,7 @@ __device__ __forceinline__ void wide_expand(cpx<float> (&v)[kWidePpl], int &zc, 
     }
 #pragma unroll
     for (int r = NZ; r < kWidePpl; ++r) v[r] = cpx<float>{0.0f, 0.0f};
+    return unsure;
 }
 
 // 1024-point complex FFT of the lane's 16 points v[r] = z[l + 64 r] into the work area Z (natural
@@ -246,18 +261,19 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     cpx<T> *AB = Z;                                               // per bin (loWt p, p - loWt p)
     T *bandE = Zt + 2 * NC;                                       // sub-band sums (general band widths)
     T *Pw = Zt;                                                   // plain power values, before AB
-    T *fbkSep = Zt + a.rawOrZElems;                               // V x P log-mel values (cepstral mode)
+    T *fbkSep = Zt + a.rawOrZElems;                               // log-mel values [channel][row], zeros up to a multiple of 4 channels (cepstral mode)
 
+    if (!a.fbankFlag) {
+        for (int i = tt0; i < ((a.P + 3) & ~3) * a.V; i += 64) fbkSep[i] = (T)0;
+    }
     if (a.tabElems > 0) {
-        const int rows = a.M + a.c0Flag, pitch = a.P + 1;
+        const int rows = a.M + a.c0Flag, pitch = a.tabPitch;
         for (int i = tid; i < rows * pitch; i += WAVES * 64) {
             const int j = i / pitch, k = i - j * pitch;
             dctL[i] = k < a.P ? a.dctT[j * a.dctPitch + k] : (T)0;
         }
         __syncthreads();
     }
-    const T *dctTab = a.tabElems > 0 ? dctL : a.dctT;
-    const int dctPitch = a.tabElems > 0 ? a.P + 1 : a.dctPitch;
     // Per-lane constants.  The window pairs stay in registers for the whole launch.  The twiddle
     // factors of the second and third FFT stage and the split factors are read (through L1, the
     // same few KB for every wave) before the round's first FFT stage, the filterbank weights after
@@ -271,6 +287,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     const int4 *lseg = reinterpret_cast<const int4 *>(a.laneSeg);
     const int4 part0 = lseg[l], part1 = lseg[64 + l], chanParts = lseg[128 + l];
     const float kf = (float)a.preK;
+    const float zcThr = (float)(4.0 * __builtin_fabs((double)kf - a.preK)) + 1e-12f;
     const int JW = a.M + a.c0Flag;
     const int F_V = a.V, F_S = a.S;
 
@@ -397,11 +414,23 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             //      the signal's first sample), Ham main.c:229, te mfcc.c:138-142
             cpx<T> v[PPL];
             int zc = 0;
+            bool unsure;
             switch (vv) { // (the same for every lane)
-            case 0: wide_expand<NZ, ZC, 0>(v, zc, raw, l, wreg, a.preK, kf, firstTile, a.wlen); break;
-            case 1: wide_expand<NZ, ZC, 1>(v, zc, raw, l, wreg, a.preK, kf, firstTile, a.wlen); break;
-            case 2: wide_expand<NZ, ZC, 2>(v, zc, raw, l, wreg, a.preK, kf, firstTile, a.wlen); break;
-            default: wide_expand<NZ, ZC, 3>(v, zc, raw, l, wreg, a.preK, kf, firstTile, a.wlen); break;
+            case 0: unsure = wide_expand<NZ, ZC, 0, false>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+            case 1: unsure = wide_expand<NZ, ZC, 1, false>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+            case 2: unsure = wide_expand<NZ, ZC, 2, false>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+            default: unsure = wide_expand<NZ, ZC, 3, false>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+            }
+            if constexpr (ZC) {
+                if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) {
+                    zc = 0;
+                    switch (vv) {
+                    case 0: wide_expand<NZ, ZC, 0, true>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+                    case 1: wide_expand<NZ, ZC, 1, true>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+                    case 2: wide_expand<NZ, ZC, 2, true>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+                    default: wide_expand<NZ, ZC, 3, true>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+                    }
+                }
             }
             T te = 0;
             if (a.energyFlag) {
@@ -484,9 +513,9 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) Pw[g * 64 + l] = pass == 0 ? e[g] : ek[g];
+                    for (int g = 0; g < 16; ++g) Pw[g * 68 + l] = pass == 0 ? e[g] : ek[g]; // (rows of 64 + 4: the reads below then spread over the banks)
                     group_sync<G>();
-                    const float4 *q4 = reinterpret_cast<const float4 *>(Pw + (l & 15) * 64 + (l >> 4) * 16);
+                    const float4 *q4 = reinterpret_cast<const float4 *>(Pw + (l & 15) * 68 + (l >> 4) * 16);
                     const float4 s0 = q4[0], s1 = q4[1], s2 = q4[2], s3 = q4[3];
                     T sum = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
                             (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
@@ -605,16 +634,16 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             group_sync<G>();
             T lv = 0;
             if (l < a.P) {
-                // (at most 8 parts per segment: all reads go out together, the sums stay in part order)
-                T pu[8], pt[8];
+                // (at most 10 parts per segment: all reads go out together, the sums stay in part order)
+                T pu[10], pt[10];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 10; ++j) {
                     pu[j] = Pw[128 + chanParts.x + j];
                     pt[j] = Pw[chanParts.z + j];
                 }
                 T mu = 0, mt = 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 10; ++j) {
                     mu += j < chanParts.y ? pu[j] : (T)0;
                     mt += j < chanParts.w ? pt[j] : (T)0;
                 }
@@ -628,38 +657,56 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             }
             if (l < a.P) {
                 if (a.fbankFlag) fo[l] = lv;
-                else fbkSep[vv * a.P + l] = lv;
+                else fbkSep[l * F_V + vv] = lv; // [channel][row]
             }
             team_sync<TEAM>(); // the work area is free for the next round, the raw bytes are in place
             STAMP(6);
         }
         if (LAST && !a.fbankFlag) {
             // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208) of the frame's
-            //      rows as 16 x 16 x 4 matrix-core products: lane (i, g) = (lane % 16, lane / 16) feeds
-            //      fbk[row i][k0 + g] and dct[coefficient i][k0 + g] and holds the results of rows
-            //      4 g .. 4 g + 3 for coefficient i.  The table's row M is all ones (C0).
-            const int i16 = tt & 15, g4 = tt >> 4;
-            for (int jb = 0; jb * 16 < JW; ++jb) {
-                const int jB = jb * 16 + i16;
-                const T *fa = fbkSep + (i16 < F_V ? i16 : 0) * a.P;
-                const T *db = dctTab + (jB < JW ? jB : 0) * dctPitch;
-                Acc4<T> acc = {0, 0, 0, 0};
-                T bvs[16]; // the block's table values first (read through L1), then the products
+            //      rows: lane j forms coefficient j of every row from its table row (row M is all
+            //      ones: C0) and the frame's log-mel values, which all lanes read together.
+            //      (One instance per row count and per place of the table: plain LDS or global reads.)
+            const int P4 = (a.P + 3) & ~3;
+            auto cepstra = [&](auto rowsTag, auto paddedTag, const T *table, const int pitch) {
+                constexpr int VV = decltype(rowsTag)::value;
+                constexpr bool PADDED = decltype(paddedTag)::value; // table rows hold zeros up to P4
+                for (int j0 = 0; j0 < JW; j0 += 64) {
+                    const int j = j0 + l;
+                    const T *row = table + (j < JW ? j : JW - 1) * pitch;
+                    T acc[VV];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) bvs[i] = (4 * i < a.P && jB < JW) ? db[4 * i + g4] : (T)0;
+                    for (int v = 0; v < VV; ++v) acc[v] = 0;
+                    for (int k0 = 0; k0 < P4; k0 += 4) {
+                        T tv[4], f[4 * VV];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int k = 4 * i + g4;
-                    if (4 * i < a.P) {
-                        T fv = fa[k < a.P ? k : 0];
-                        fv = (i16 < F_V && k < a.P) ? fv : (T)0;
-                        acc = mfma16(fv, bvs[i], acc);
+                        for (int u = 0; u < 4; ++u) tv[u] = row[PADDED ? k0 + u : min(k0 + u, a.P - 1)];
+#pragma unroll
+                        for (int v = 0; v < VV; ++v) {
+                            const float4 q = *reinterpret_cast<const float4 *>(fbkSep + k0 * VV + 4 * v);
+                            f[4 * v] = q.x, f[4 * v + 1] = q.y, f[4 * v + 2] = q.z, f[4 * v + 3] = q.w;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int v = 0; v < VV; ++v) acc[v] += tv[u] * f[u * VV + v];
+                    }
+                    if (j < JW) {
+#pragma unroll
+                        for (int v = 0; v < VV; ++v) outRow[v * a.D + j] = acc[v] * a.mfnorm;
                     }
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (g4 == 0 && r < F_V && jB < JW) outRow[r * a.D + jB] = acc[r] * a.mfnorm;
-            }
+            };
+            auto cepstra_rows = [&](auto paddedTag, const T *table, const int pitch) {
+                switch (F_V) {
+                case 1: cepstra(std::integral_constant<int, 1>{}, paddedTag, table, pitch); break;
+                case 2: cepstra(std::integral_constant<int, 2>{}, paddedTag, table, pitch); break;
+                case 3: cepstra(std::integral_constant<int, 3>{}, paddedTag, table, pitch); break;
+                default: cepstra(std::integral_constant<int, 4>{}, paddedTag, table, pitch); break;
+                }
+            };
+            if (a.tabElems > 0) cepstra_rows(std::true_type{}, dctL, a.tabPitch);
+            else cepstra_rows(std::false_type{}, a.dctT, a.dctPitch);
             team_sync<TEAM>();
         }
         STAMP(9);

@@ -22,7 +22,7 @@ from collections import defaultdict
 
 w, frames, utts = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
 src = sys.argv[4] if len(sys.argv) > 4 else "gpurun_out/profiles_r2/" + w
-KERNELS = ("k_lean256", "k_front")
+KERNELS = ("k_lean256", "k_wide1024", "k_front")
 
 
 def counters(dirname):
