@@ -87,25 +87,18 @@ __device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, 
 {
     constexpr int G = kWideG;
     float nextFirst0 = 0; // sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r)
-    bool unsure = false;
-    // All reads first (the first 12 of the 18 bytes; the other 6 are the next lane's first 6 and
-    // come by lane shift, for lane 63 from lane 0's next pair), then the arithmetic.
-    unsigned own[NZ][3];
+    float margin = 1.0f;  // least |y| - zcThr |predecessor| over the lane's samples (EXACT off)
+    // All reads first, then the arithmetic.
+    unsigned own[NZ][5];
 #pragma unroll
     for (int r = 0; r < NZ; ++r) {
         const unsigned *src = raw + 3 * (l + G * r);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) own[r][i] = src[i];
+        for (int i = 0; i < 5; ++i) own[r][i] = src[i];
     }
-    unsigned top0 = raw[3 * G * NZ], top1 = raw[3 * G * NZ + 1]; // (past the frame when wlen < 128 NZ: unused then)
 #pragma unroll
     for (int r = NZ - 1; r >= 0; --r) {
-        unsigned d[5];
-        d[0] = own[r][0], d[1] = own[r][1], d[2] = own[r][2];
-        d[3] = (unsigned)__builtin_amdgcn_update_dpp((int)top0, (int)own[r][0], 0x130, 0xf, 0xf, false);
-        d[4] = (unsigned)__builtin_amdgcn_update_dpp((int)top1, (int)own[r][1], 0x130, 0xf, 0xf, false);
-        top0 = (unsigned)sgpr((int)own[r][0]);
-        top1 = (unsigned)sgpr((int)own[r][1]);
+        const unsigned(&d)[5] = own[r];
         int c[3];
         if constexpr (ROW == 0) {
             c[0] = sample24<0, 5>(d), c[1] = sample24<6, 5>(d), c[2] = sample24<12, 5>(d);
@@ -134,18 +127,24 @@ __device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, 
             } else {
                 y1 = __builtin_fmaf(-kf, x[0], x[1]);
                 y2 = __builtin_fmaf(-kf, x[1], x[2]);
-                // (strictly below: a zero sample after a zero predecessor is exact)
-                unsure |= __builtin_fabsf(y1) < zcThr * __builtin_fabsf(x[0]) || __builtin_fabsf(y2) < zcThr * __builtin_fabsf(x[1]);
+                // (a zero sample after a zero predecessor is exact: margin 0, not below it)
+                margin = __builtin_fminf(margin, __builtin_fminf(__builtin_fmaf(-zcThr, __builtin_fabsf(x[0]), __builtin_fabsf(y1)),
+                                                                 __builtin_fmaf(-zcThr, __builtin_fabsf(x[1]), __builtin_fabsf(y2))));
             }
             if (firstTile && l == 0 && r == 0) y1 = (float)((double)x[1] * (1.0 - preK)); // s[1] *= 1 - k
             // sample 2n+2 is the first sample of the next lane's pair (lane 63: of lane 0's next pair)
-            const int s0 = 2 * (l + G * r);
             const float x2 = wave_shl1f(y1, nextFirst0);
             // (opposite signs = negative product; the samples are far from the underflow range)
-            const bool c01 = y1 * y2 < 0.0f;
-            const bool c12 = y2 * x2 < 0.0f;
-            zc += (c01 && s0 + 1 < wlen) ? 1 : 0; // pairs inside the frame only
-            zc += (c12 && s0 + 2 < wlen) ? 1 : 0;
+            bool c01 = y1 * y2 < 0.0f, c12 = y2 * x2 < 0.0f;
+            // pairs inside the frame only.  (The instance with 14 inputs per lane runs only for
+            // 128 * 13 < wlen <= 128 * 14: every r below the last lies inside the frame.)
+            if (r == NZ - 1 || NZ != 14) {
+                const int s0 = 2 * (l + G * r);
+                c01 = c01 && s0 + 1 < wlen;
+                c12 = c12 && s0 + 2 < wlen;
+            }
+            // counted over the wave at once: zc is the same in every lane
+            zc += __builtin_popcountll(__builtin_amdgcn_ballot_w64(c01)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c12));
             nextFirst0 = __builtin_bit_cast(float, sgpr(__builtin_bit_cast(int, y1)));
         } else {
             float x[3];
@@ -159,7 +158,7 @@ __device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, 
     }
 #pragma unroll
     for (int r = NZ; r < kWidePpl; ++r) v[r] = cpx<float>{0.0f, 0.0f};
-    return unsure;
+    return margin < 0.0f;
 }
 
 // 1024-point complex FFT of the lane's 16 points v[r] = z[l + 64 r] into the work area Z (natural
@@ -439,7 +438,6 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                 for (int r = 0; r < NZ; ++r) e2 += v[r] * v[r];
                 te = group_sum<T, G>((T)4 * (e2.x + e2.y), nullptr, tt); // (half-scaled window)
             }
-            if constexpr (ZC) zc = group_sum<int, G>(zc, nullptr, tt);
             STAMP(1);
             cpx<T> twB[15], twC[12], swreg[NPAIR];
 #pragma unroll
