@@ -72,6 +72,16 @@ typedef struct MFCCConfig {
     char fileList[MFCC_MAX_PATH];
     int numDevices; /* GPUs MFCCWapperList spreads its batches over ([IO] numDevices): 0 = all visible;
                        -k = k device threads round-robin over the visible GPUs (several streams per GPU) */
+    /* Options the reference carries but fixes in its one call of InitFBank (main.c:168) or leaves
+     * commented out; MFCCConfigDefaults sets the reference's values (1, 1, 0, 1.0, 0, 0, 0).  ini keys
+     * of the same names in [MFCC] (normEnergy in [Regression]). */
+    int usePower;      /* 0: magnitude instead of power into the filterbank (mfcc.c:154-157) */
+    int takeLogs;      /* 0: filterbank sums without floor and log (mfcc.c:171-176) */
+    int doubleFFT;     /* 1: FFT of twice the usual length (mfcc.c:55-56) */
+    double warpAlpha;  /* vocal tract length warping factor of the channel centres (mfcc.c:17-36,83-92) */
+    double warpLowCut; /* its lower and upper cut-off frequencies in Hz */
+    double warpUpCut;
+    int normEnergy;    /* 1: NormaliseLogEnergy(column MFCCNum, 50 dB, 0.1) before the regression (main.c:255) */
 } MFCCConfig;
 
 /* Thread-local message of the last failed call ("" if none). */

@@ -50,6 +50,13 @@ class MFCCConfig(C.Structure):
         ("precision", C.c_int),
         ("fileList", C.c_char * MAX_PATH),
         ("numDevices", C.c_int),
+        ("usePower", C.c_int),
+        ("takeLogs", C.c_int),
+        ("doubleFFT", C.c_int),
+        ("warpAlpha", C.c_double),
+        ("warpLowCut", C.c_double),
+        ("warpUpCut", C.c_double),
+        ("normEnergy", C.c_int),
     ]
 
 

@@ -297,12 +297,14 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
     // fastest on MI355X where that variant exists, 16 otherwise
     // Lean candidates (see k_front) run 16 points per lane at two workgroups per CU: measured
     // slightly ahead of 8 points at three (6.46 vs 6.63 ms on 10,000 ten-second utterances).
-    const bool leanCand = prec == MFCC_PREC_F32 && p->channels == 1 && p->bps == 2 && V == 1 &&
+    // (magnitude instead of power and sums without logs: the general kernel only)
+    const bool plainFbank = c->cfg.usePower && c->cfg.takeLogs;
+    const bool leanCand = plainFbank && prec == MFCC_PREC_F32 && p->channels == 1 && p->bps == 2 && V == 1 &&
                           c->cfg.inc % 2 == 0 && !c->cfg.zeroCrossingFlag && !c->cfg.brightFlag &&
                           !c->cfg.subBandEFlag && !c->cfg.fftLength && !c->cfg.zeroMeanSigFlag &&
                           !tune.noLean;
     // 24-bit stereo with 1024 complex points: k_wide1024 (16 points per lane, wave-sized teams)
-    const bool wideCand = allowWide && prec == MFCC_PREC_F32 && !c->cfg.zeroMeanSigFlag && !c->cfg.fftLength &&
+    const bool wideCand = plainFbank && allowWide && prec == MFCC_PREC_F32 && !c->cfg.zeroMeanSigFlag && !c->cfg.fftLength &&
                           p->totalRows < 0x7fffffffLL && !tune.noLean &&
                           wide1024_applies(log2nc, p->channels, p->bps, c->cfg.wlen) && c->cfg.bankNum <= 64;
     int pplog = (front_variant_exists(log2nc, 3) && !leanCand && !wideCand) ? 3 : 4;
@@ -1002,6 +1004,8 @@ extern "C" int MFCCPlanCreateShard(MFCCContext *c, int channels, int bytesPerSam
     if (c->cfg.vecNum > rows) return set_error("vecnum %d > num_channels %d", c->cfg.vecNum, channels), MFCC_E_VECNUM;
     if (c->cfg.zeroMeanSigFlag && !chanSum2)
         return set_error("zeroMeanSigFlag needs chanSum2 for a shard plan"), MFCC_E_ARG;
+    if (c->cfg.normEnergy)
+        return set_error("normEnergy needs the whole recording's maximum: not available for frame shards"), MFCC_E_CONFIG;
     std::unique_ptr<MFCCPlan> p(new MFCCPlan);
     p->ctx = c;
     p->shard = true;
@@ -1129,6 +1133,8 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.step = outStep; // row pitch of outDev: the full row, or vSize for the compact static buffer
     a.c0Flag = c->c0;
     a.energyFlag = c->cfg.energyFlag;
+    a.usePower = c->cfg.usePower ? 1 : 0;
+    a.takeLogs = c->cfg.takeLogs ? 1 : 0;
     a.zcFlag = c->cfg.zeroCrossingFlag;
     a.brightFlag = c->cfg.brightFlag;
     a.S = c->cfg.subBandEFlag;
@@ -1385,6 +1391,10 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
     if (p->timing) {
         HIP_TRY(hipEventRecord(p->evStop, st));
         p->timed = true;
+    }
+    if (c->cfg.normEnergy) { // main.c:255: the first row's column behind its coefficients, 50 dB, 0.1
+        const int e = launch_energy_norm(c->cfg.precision, frontOut, p->dUtts, p->numUtts, frontStep, c->M, 50.0, 0.1, stream);
+        if (e) return set_error("energy normalisation kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
     }
     if (p->uttFinish) return f64 ? run_finish<double>(c, p, outDev, stream) : run_finish<float>(c, p, outDev, stream);
     const bool fused = p->deltaSubRows > 0;

@@ -75,6 +75,13 @@ static int apply_key(MFCCConfig *c, const char *section, const char *name, const
     else if (is("MFCC", "bankNum")) c->bankNum = atoi(value);
     else if (is("MFCC", "MFCCNum")) c->MFCCNum = atoi(value);
     else if (is("MFCC", "MFCC0thFlag")) c->MFCC0thFlag = atoi(value);
+    else if (is("MFCC", "usePower")) c->usePower = atoi(value);
+    else if (is("MFCC", "takeLogs")) c->takeLogs = atoi(value);
+    else if (is("MFCC", "doubleFFT")) c->doubleFFT = atoi(value);
+    else if (is("MFCC", "warpAlpha")) c->warpAlpha = atof(value);
+    else if (is("MFCC", "warpLowCut")) c->warpLowCut = atof(value);
+    else if (is("MFCC", "warpUpCut")) c->warpUpCut = atof(value);
+    else if (is("Regression", "normEnergy")) c->normEnergy = atoi(value);
     else if (is("Others", "energyFlag")) c->energyFlag = atoi(value);
     else if (is("Others", "zeroCrossingFlag")) c->zeroCrossingFlag = atoi(value);
     else if (is("Others", "brightFlag")) c->brightFlag = atoi(value);
@@ -110,6 +117,12 @@ int validate_config(const MFCCConfig &c)
         return set_error("energyFlag / zeroCrossingFlag / brightFlag must be 0 or 1"), MFCC_E_CONFIG;
     int fftN = 2;
     while (c.wlen > fftN) fftN *= 2;
+    if (c.doubleFFT) fftN *= 2; // mfcc.c:55-56
+    if (fftN > (2 << kMaxLog2Nc)) return set_error("doubleFFT needs an FFT longer than %d", 2 << kMaxLog2Nc), MFCC_E_CONFIG;
+    if (!(c.warpAlpha > 0.0)) return set_error("warpAlpha must be > 0 (1.0 = no warping)"), MFCC_E_CONFIG;
+    if (c.normEnergy < 0 || c.normEnergy > 1) return set_error("normEnergy must be 0 or 1"), MFCC_E_CONFIG;
+    if (c.normEnergy && eff_mfccnum(c) >= MFCCFeatureDim(&c))
+        return set_error("normEnergy needs a column behind the coefficients (MFCC0thFlag or energyFlag)"), MFCC_E_CONFIG;
     if (c.subBandEFlag > fftN / 2 || c.fftLength > fftN / 2)
         return set_error("subBandEFlag / fftLength exceed fftN/2 = %d", fftN / 2), MFCC_E_CONFIG;
     if (c.precision != MFCC_PREC_F32 && c.precision != MFCC_PREC_F64)
@@ -141,6 +154,9 @@ extern "C" int MFCCConfigDefaults(MFCCConfig *cfg)
     cfg->saveType = MFCC_SAVE_E;
     cfg->numThreads = 1;
     cfg->numDevices = 0;
+    cfg->usePower = 1; // main.c:168
+    cfg->takeLogs = 1;
+    cfg->warpAlpha = 1.0;
     cfg->precision = MFCC_PREC_F64; // the reference computes in double; single precision is the opt-in fast mode
     return MFCC_OK;
 }

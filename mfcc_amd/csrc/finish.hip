@@ -298,6 +298,52 @@ int launch_t(const FinishArgs<T> &a, int orders, int numUtts, size_t lds, hipStr
 
 } // namespace
 
+// NormaliseLogEnergy of one column (the commented call main.c:255; HTK's definition, the source
+// being absent from the reference's snapshot): per utterance, the column's largest value becomes
+// 1, values more than silFloor dB below it are raised to that floor first, differences are scaled
+// by escale.  One workgroup per utterance; the arithmetic is double as the reference's is.
+template <typename T>
+__global__ __launch_bounds__(256) void k_energy_norm(T *data, const UttDesc *utts, int step, int col, double silFloor,
+                                                      double escale)
+{
+    const UttDesc ud = utts[blockIdx.x];
+    if (ud.numFrames <= 0) return;
+    T *p = data + ud.outRow * step + col;
+    __shared__ double red[256];
+    double mx = -INFINITY;
+    for (int t = threadIdx.x; t < ud.numFrames; t += 256) {
+        const double v = (double)p[(long long)t * step];
+        mx = v > mx ? v : mx; // (as the reference's `if (*p > max)`: a NaN never becomes the maximum)
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = red[threadIdx.x + o] > red[threadIdx.x] ? red[threadIdx.x + o] : red[threadIdx.x];
+        __syncthreads();
+    }
+    mx = red[0];
+    const double mn = mx - (silFloor * log(10.0)) / 10.0;
+    for (int t = threadIdx.x; t < ud.numFrames; t += 256) {
+        double v = (double)p[(long long)t * step];
+        if (v < mn) v = mn;
+        p[(long long)t * step] = (T)(1.0 - (mx - v) * escale);
+    }
+}
+
+int launch_energy_norm(int precision, void *data, const UttDesc *utts, int numUtts, int step, int col, double silFloor,
+                       double escale, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (numUtts <= 0) return 0;
+    if (precision == 1)
+        hipLaunchKernelGGL(k_energy_norm<double>, dim3(numUtts), dim3(256), 0, st, static_cast<double *>(data), utts, step, col,
+                           silFloor, escale);
+    else
+        hipLaunchKernelGGL(k_energy_norm<float>, dim3(numUtts), dim3(256), 0, st, static_cast<float *>(data), utts, step, col,
+                           silFloor, escale);
+    return (int)hipGetLastError();
+}
+
 int launch_utt_finish(int precision, const void *args, int orders, int numUtts, size_t ldsBytes, void *stream)
 {
     if (numUtts <= 0) return 0;

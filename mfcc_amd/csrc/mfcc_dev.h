@@ -63,6 +63,7 @@ struct FrontArgs {
     int V, channels, bps;
     int P, M, D, vSize, step;
     int c0Flag, energyFlag, zcFlag, brightFlag, S, fftLength, fbankFlag;
+    int usePower, takeLogs; // mfcc.c:154-157,171-176 (both 1 at the reference's call site)
     double preK;
     T mfnorm;
     const T *window;       // wlen values, zero-padded to fftN + 8
@@ -170,6 +171,8 @@ int launch_colfinal(const StatArgs<float> &a, int numUtts, bool byBlock, void *s
 int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, double *sumsOut, void *stream);
 int launch_delta(int precision, const void *args, int orders, size_t ldsBytes, void *stream); // -2: no such variant
 int launch_utt_finish(int precision, const void *args, int orders, int numUtts, size_t ldsBytes, void *stream);
+int launch_energy_norm(int precision, void *data, const UttDesc *utts, int numUtts, int step, int col, double silFloor,
+                       double escale, void *stream);
 int launch_normalize(int precision, const void *args, int numChunks, bool shardSums,
                      const double *sums, void *stream);
 // batched pieces of the reference's lower-level API (pieces.hip)

@@ -643,10 +643,14 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
             for (int q = 0; q < NPAIR; ++q) {
                 const int k = l + G * q;
                 const int k2 = k == 0 ? NC / 2 : NC - k;
-                const T t1 = (LEAN ? lwreg[2 * q] : lw[k]) * pa[q];
-                const T t2 = (LEAN ? lwreg[2 * q + 1] : lw[k2]) * pb[q];
-                AB[k] = {t1, pa[q] - t1};
-                if (NC > 1) AB[k2] = {t2, pb[q] - t2};
+                // (magnitude instead of power when usePower is off, mfcc.c:154-157; never in the
+                // lean instantiations)
+                const T ea = (LEAN || a.usePower) ? pa[q] : tsqrt<T>(pa[q]);
+                const T eb = (LEAN || a.usePower) ? pb[q] : tsqrt<T>(pb[q]);
+                const T t1 = (LEAN ? lwreg[2 * q] : lw[k]) * ea;
+                const T t2 = (LEAN ? lwreg[2 * q + 1] : lw[k2]) * eb;
+                AB[k] = {t1, ea - t1};
+                if (NC > 1) AB[k2] = {t2, eb - t2};
             }
             group_sync<G>();
 
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                     mt += Tt[j * (a.P + 1) + ch + 1];
                 }
                 const T m = mu + mt;
-                const T lv = tlog<T>(m < (T)1 ? (T)1 : m);
+                const T lv = (LEAN || a.takeLogs) ? tlog<T>(m < (T)1 ? (T)1 : m) : m; // mfcc.c:171-176
                 if (active && a.fbkElems) fbk[ch] = lv;
                 if (active && a.fbankFlag) fo[ch] = lv;
             }

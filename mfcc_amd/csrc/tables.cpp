@@ -91,7 +91,8 @@ int build_tables(const MFCCConfig &cfg, Tables &t)
 {
     const double sampPeriod = 1e7 / (double)cfg.sampleRate; // main.c:141
     const int P = cfg.bankNum;
-    build_fbank(cfg.wlen, sampPeriod, P, cfg.lowpassfre, cfg.hipassfre, t, 0, 1.0, 0.0, 0.0); // main.c:168
+    build_fbank(cfg.wlen, sampPeriod, P, cfg.lowpassfre, cfg.hipassfre, t, cfg.doubleFFT, cfg.warpAlpha, cfg.warpLowCut,
+                cfg.warpUpCut); // main.c:168 passes 0, 1.0, 0, 0
     // Hamming window: HTK GenHamWindow, w[i] = 0.54 - 0.46 cos(2 pi (i-1) / (W-1))
     t.window.resize(cfg.wlen);
     {

@@ -35,6 +35,13 @@ class OrcConfig(C.Structure):
         ("delwin", C.c_int),
         ("zeroMeanSigFlag", C.c_int),
         ("znormFlag", C.c_int),
+        ("usePower", C.c_int),
+        ("takeLogs", C.c_int),
+        ("doubleFFT", C.c_int),
+        ("warpAlpha", C.c_double),
+        ("warpLowCut", C.c_double),
+        ("warpUpCut", C.c_double),
+        ("normEnergy", C.c_int),
     ]
 
 
@@ -52,6 +59,8 @@ class OrcFBank(C.Structure):
         ("cf", C.POINTER(C.c_double)),
         ("loChan", C.POINTER(C.c_int)),
         ("loWt", C.POINTER(C.c_double)),
+        ("usePower", C.c_int),
+        ("takeLogs", C.c_int),
     ]
 
 
@@ -80,6 +89,11 @@ def lib():
     L.orc_mel.argtypes = [C.c_int, C.c_double]
     L.orc_fbank_init.argtypes = [C.POINTER(OrcFBank), C.c_int, C.c_double, C.c_int, C.c_double,
                                  C.c_double]
+    L.orc_fbank_init_ex.argtypes = [C.POINTER(OrcFBank), C.c_int, C.c_double, C.c_int, C.c_double,
+                                    C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                    C.c_double]
+    L.orc_normalise_log_energy.argtypes = [dp, C.c_long, C.c_int, C.c_double, C.c_double]
+    L.orc_normalise_log_energy.restype = None
     L.orc_fbank_free.argtypes = [C.POINTER(OrcFBank)]
     L.orc_fbank_passband_text.argtypes = [C.POINTER(OrcFBank), C.c_char_p, C.c_size_t]
     L.orc_fft.argtypes = [dp, C.c_int, C.c_int]
@@ -126,7 +140,8 @@ _CFG_DEFAULTS = dict(
     sampleRate=16000, hipassfre=-1.0, lowpassfre=-1.0, preemphasise=0.0, wlen=400, inc=160,
     vecNum=1, fbankFlag=1, bankNum=40, MFCCNum=13, MFCC0thFlag=0, energyFlag=0,
     zeroCrossingFlag=0, brightFlag=0, subBandEFlag=0, fftLength=0, regreOrder=1, delwin=2,
-    zeroMeanSigFlag=0, znormFlag=0)
+    zeroMeanSigFlag=0, znormFlag=0, usePower=1, takeLogs=1, doubleFFT=0, warpAlpha=1.0,
+    warpLowCut=0.0, warpUpCut=0.0, normEnergy=0)
 
 
 def make_config(**kw):

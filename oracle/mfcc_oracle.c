@@ -27,15 +27,39 @@ double orc_mel(int k, double fres) /* mfcc.c:11-14, k is the reference's 1-based
     return 1127 * log(1 + (k - 1) * fres);
 }
 
+double orc_warp_freq(double fcl, double fcu, double freq, double minFreq, double maxFreq,
+                     double alpha) /* mfcc.c:17-36 */
+{
+    if (alpha == 1.0) return freq;
+    const double scale = 1.0 / alpha;
+    const double cu = fcu * 2 / (1 + scale);
+    const double cl = fcl * 2 / (1 + scale);
+    const double au = (maxFreq - cu * scale) / (maxFreq - cu);
+    const double al = (cl * scale - minFreq) / (cl - minFreq);
+    if (freq > cu) return au * (freq - cu) + scale * cu;
+    if (freq < cl) return al * (freq - minFreq) + minFreq;
+    return scale * freq;
+}
+
 int orc_fbank_init(orc_fbank *fb, int frameSize, double sampPeriod, int numChans, double lopass,
-                   double hipass)
+                   double hipass) /* the call of main.c:168 */
+{
+    return orc_fbank_init_ex(fb, frameSize, sampPeriod, numChans, lopass, hipass, 1, 1, 0, 1.0, 0.0, 0.0);
+}
+
+int orc_fbank_init_ex(orc_fbank *fb, int frameSize, double sampPeriod, int numChans, double lopass,
+                      double hipass, int usePower, int takeLogs, int doubleFFT, double alpha,
+                      double warpLowCut, double warpUpCut)
 {
     memset(fb, 0, sizeof *fb);
     fb->frameSize = frameSize;
     fb->numChans = numChans;
     fb->sampPeriod = sampPeriod;
+    fb->usePower = usePower; /* mfcc.c:52 */
+    fb->takeLogs = takeLogs;
     fb->fftN = 2; /* mfcc.c:53-54 */
     while (frameSize > fb->fftN) fb->fftN *= 2;
+    if (doubleFFT) fb->fftN *= 2; /* mfcc.c:55-56 */
     const int half = fb->fftN / 2;
     fb->fres = 1.0E7 / (sampPeriod * fb->fftN * 700.0); /* mfcc.c:58 */
     const int maxChan = numChans + 1;
@@ -57,9 +81,19 @@ int orc_fbank_init(orc_fbank *fb, int frameSize, double sampPeriod, int numChans
     fb->loChan = (int *)calloc((size_t)half, sizeof(int));
     fb->loWt = (double *)calloc((size_t)half, sizeof(double));
     if (!fb->cf || !fb->loChan || !fb->loWt) return -1;
-    const double ms = fb->mhi - fb->mlo; /* mfcc.c:78-82, alpha == 1.0 branch */
-    for (int chan = 1; chan <= maxChan; chan++)
-        fb->cf[chan - 1] = ((double)chan / (double)maxChan) * ms + fb->mlo;
+    const double ms = fb->mhi - fb->mlo; /* mfcc.c:78-93 */
+    for (int chan = 1; chan <= maxChan; chan++) {
+        if (alpha == 1.0) {
+            fb->cf[chan - 1] = ((double)chan / (double)maxChan) * ms + fb->mlo;
+        } else { /* scale assuming scaling starts at lopass */
+            const double minFreq = 700.0 * (exp(fb->mlo / 1127.0) - 1.0);
+            const double maxFreq = 700.0 * (exp(fb->mhi / 1127.0) - 1.0);
+            double cf = ((double)chan / (double)maxChan) * ms + fb->mlo;
+            cf = 700 * (exp(cf / 1127.0) - 1.0);
+            fb->cf[chan - 1] =
+                1127.0 * log(1.0 + orc_warp_freq(warpLowCut, warpUpCut, cf, minFreq, maxFreq, alpha) / 700.0);
+        }
+    }
     /* mfcc.c:96-104: lower channel of every bin, -1 outside the pass band */
     for (int k = 1, chan = 1; k <= half; k++) {
         const double melk = orc_mel(k, fb->fres);
@@ -176,7 +210,7 @@ void orc_realft(double *s, int n)
 
 /* ---------------------------------------------------------------- per-frame analysis */
 
-/* mfcc.c:125-177 with usePower=1, takeLogs=1 (the only call site, main.c:168).  x is the fftN
+/* mfcc.c:125-177.  x is the fftN
  * workspace and keeps the packed spectrum on return, as info.x does in the reference. */
 void orc_wave2fbank(const double *s, double *fbank, double *te, double *te2, const orc_fbank *fb,
                     double *x)
@@ -192,7 +226,7 @@ void orc_wave2fbank(const double *s, double *fbank, double *te, double *te2, con
     for (int b = 0; b < fb->numChans; b++) fbank[b] = 0.0;
     for (int k = fb->klo; k <= fb->khi; k++) { /* 1-based bin k: re x[2k-2], im x[2k-1] */
         double t1 = x[2 * k - 2], t2 = x[2 * k - 1];
-        const double ek = t1 * t1 + t2 * t2;
+        const double ek = fb->usePower ? t1 * t1 + t2 * t2 : sqrt(t1 * t1 + t2 * t2); /* mfcc.c:154-157 */
         const int bin = fb->loChan[k - 1];
         t1 = fb->loWt[k - 1] * ek;
         if (bin > 0) fbank[bin - 1] += t1;
@@ -203,11 +237,12 @@ void orc_wave2fbank(const double *s, double *fbank, double *te, double *te2, con
         for (int k = 1; k <= fb->fftN / 2; k++)
             *te2 += x[2 * k - 2] * x[2 * k - 2] + x[2 * k - 1] * x[2 * k - 1];
     }
-    for (int b = 0; b < fb->numChans; b++) {
-        double t1 = fbank[b];
-        if (t1 < melfloor) t1 = melfloor;
-        fbank[b] = log(t1);
-    }
+    if (fb->takeLogs) /* mfcc.c:171-176 */
+        for (int b = 0; b < fb->numChans; b++) {
+            double t1 = fbank[b];
+            if (t1 < melfloor) t1 = melfloor;
+            fbank[b] = log(t1);
+        }
 }
 
 void orc_fbank2mfcc(const double *fbank, int numChan, double *c, int n) /* mfcc.c:180-195 */
@@ -328,6 +363,21 @@ void orc_znorm(double *data, int ncol, long n, int step)
 
 /* ---------------------------------------------------------------- per-file body */
 
+/* HTK HSigP NormaliseLogEnergy: the largest value of the column becomes 1, values more than
+ * silFloor dB below it are raised to that floor, differences are scaled by escale. */
+void orc_normalise_log_energy(double *data, long n, int step, double silFloor, double escale)
+{
+    double max = data[0];
+    for (long i = 1; i < n; i++)
+        if (data[(size_t)i * step] > max) max = data[(size_t)i * step];
+    const double min = max - (silFloor * log(10.0)) / 10.0;
+    for (long i = 0; i < n; i++) {
+        double *p = data + (size_t)i * step;
+        if (*p < min) *p = min;
+        *p = 1.0 - (max - *p) * escale;
+    }
+}
+
 long orc_num_frames(long numSamples, int wlen, int inc) /* main.c:211 == trip count of :217 */
 {
     if (numSamples < wlen) return 0;
@@ -356,8 +406,9 @@ int orc_extract(const orc_config *c, const int32_t *pcm, int numChannels, long n
     const long N = numSamples;
 
     orc_fbank fb;
-    if (orc_fbank_init(&fb, c->wlen, 1e7 / (double)c->sampleRate, c->bankNum, c->lowpassfre,
-                       c->hipassfre))
+    if (orc_fbank_init_ex(&fb, c->wlen, 1e7 / (double)c->sampleRate, c->bankNum, c->lowpassfre,
+                          c->hipassfre, c->usePower, c->takeLogs, c->doubleFFT, c->warpAlpha,
+                          c->warpLowCut, c->warpUpCut))
         return -1;
     double *d1 = (double *)malloc(sizeof(double) * (size_t)rows * (size_t)(N > 0 ? N : 1));
     double *ham = (double *)malloc(sizeof(double) * (size_t)c->wlen);
@@ -409,6 +460,8 @@ int orc_extract(const orc_config *c, const int32_t *pcm, int numChannels, long n
         }
         for (int q = 0; q < vSize * (c->regreOrder - 1); q++) out[pos++] = 0.0; /* main.c:249 */
     }
+    /* main.c:255 (commented out there): the column behind the first row's coefficients */
+    if (c->normEnergy && T > 0) orc_normalise_log_energy(out + M, T, step, 50.0, 0.1);
     if (c->regreOrder >= 2) orc_regress(out, vSize, T, step, vSize, c->delwin);
     if (c->regreOrder >= 3) orc_regress(out + vSize, vSize, T, step, vSize, c->delwin);
     if (c->znormFlag && T > 0) orc_znorm(out, step, T, step);

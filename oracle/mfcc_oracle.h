@@ -45,6 +45,16 @@ typedef struct {
     int delwin;
     int zeroMeanSigFlag;
     int znormFlag;
+    /* Options the reference carries but main.c leaves at fixed values or commented out: the
+     * InitFBank arguments of main.c:168 (usePower = 1, takeLogs = 1, doubleFFT = 0, alpha = 1.0,
+     * warp cut-offs 0) and the NormaliseLogEnergy call of main.c:255 (normEnergy = 0: as shipped). */
+    int usePower;
+    int takeLogs;
+    int doubleFFT;
+    double warpAlpha;
+    double warpLowCut;
+    double warpUpCut;
+    int normEnergy;
 } orc_config;
 
 /* FBankInfo of mfcc.h:14-27 with 0-based tables: entry [k-1] holds the reference's [k]. */
@@ -54,11 +64,18 @@ typedef struct {
     double *cf;    /* numChans+1 centre frequencies (mel) */
     int *loChan;   /* fftN/2 */
     double *loWt;  /* fftN/2 */
+    int usePower, takeLogs; /* mfcc.c:52 */
 } orc_fbank;
 
 double orc_mel(int k, double fres);                                   /* mfcc.c:11-14 */
 int orc_fbank_init(orc_fbank *fb, int frameSize, double sampPeriod, int numChans,
                    double lopass, double hipass);                     /* mfcc.c:39-122 */
+/* All eleven arguments of InitFBank (mfcc.c:39-42); WarpFreq is mfcc.c:17-36. */
+int orc_fbank_init_ex(orc_fbank *fb, int frameSize, double sampPeriod, int numChans,
+                      double lopass, double hipass, int usePower, int takeLogs, int doubleFFT,
+                      double alpha, double warpLowCut, double warpUpCut);
+double orc_warp_freq(double fcl, double fcu, double freq, double minFreq, double maxFreq,
+                     double alpha);                                   /* mfcc.c:17-36 */
 void orc_fbank_free(orc_fbank *fb);
 /* The two lines mfcc.c:74-75 print, formatted into buf. */
 int orc_fbank_passband_text(const orc_fbank *fb, char *buf, size_t cap);
@@ -77,6 +94,9 @@ double orc_brightness(const double *x, int fftN);                     /* call si
 void orc_subband(const double *x, int fftN, double *sub, int nsub);   /* call site main.c:236 */
 void orc_regress(double *data, int vSize, long n, int step, int offset, int delwin); /* main.c:259-260 */
 void orc_znorm(double *data, int ncol, long n, int step);             /* commented call main.c:264 */
+/* Commented call main.c:255; its source is absent from the snapshot: HTK HSigP's definition
+ * (the README names HTK as the model, README.md:143).  PARITY UNPINNED. */
+void orc_normalise_log_energy(double *data, long n, int step, double silFloor, double escale);
 
 long orc_num_frames(long numSamples, int wlen, int inc);              /* main.c:211,217 */
 int orc_feature_dim(const orc_config *c);                             /* main.c:161,185: per-vec D */

@@ -274,6 +274,34 @@ def test_zcr_is_exact_on_near_cancelling_samples(oracle):
     assert np.array_equal(got[:, 40], ref[:, 40].astype(np.float32).astype(np.float64))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("vec_num", [2, 4])
+@pytest.mark.parametrize("density", [1, 40])
+def test_zcr_is_exact_on_near_cancelling_stereo_24_bit_samples(oracle, vec_num, density):
+    """The same for 24-bit stereo frames of 2048 points (left, right, mid and side rows): the
+    kernel takes the signs from single-precision samples and redoes a frame in double when one of
+    its samples is too close to zero to be sure.  density 1: every other sample cancels (every
+    frame is redone); density 40: one pair in 40 (a mix of both paths)."""
+    kw = dict(CONFIGS["c4"], vecNum=vec_num)
+    rng = np.random.default_rng(17 + density)
+    n = 40000
+    x = rng.integers(-8000000, 8000000, size=(n, 2)).astype(np.int64)
+    idx = np.arange(0, n - 1, 2 * density)
+    x[idx] = x[idx] // 200 * 200
+    x[idx + 1] = x[idx] * 97 // 100  # exactly 0.97 x[i-1] in integers, in both channels (so in mid and side too)
+    pcm = np.zeros((n, 2, 3), dtype=np.uint8)
+    for b in range(3):
+        pcm[:, :, b] = (x >> (8 * b)) & 0xff
+    pcm = pcm.reshape(-1)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 2, 3)
+    got = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], 2, 3)[0]
+    kinds = column_kinds(kw)
+    d = len(kinds)
+    zc = kinds.index("zc")
+    cols = [v * d + zc for v in range(vec_num)]
+    assert np.array_equal(got[:, cols], ref[:, cols].astype(np.float32).astype(np.float64))
+
+
 def test_wapper_entry_points_and_writers(oracle, tmp_path):
     """MFCCWapper / MFCCWapperMem / MFCCWapperList end to end: files in, files out."""
     kw = dict(CONFIGS["c3"])
@@ -601,64 +629,76 @@ def test_file_sharded_whole_run(tmp_path):
 def test_init_fbank_with_warping_and_double_fft(oracle):
     """InitFBank's options that main.c:168 leaves off (doubleFFT, alpha with warpLowCut/warpUpCut,
     mfcc.c:17-36,55-56,83-92) and FBankInfo's usePower = 0 / takeLogs = 0 (mfcc.c:154-157,171-176),
-    through the reference-named functions: tables against a restatement of those lines here,
-    Wave2FBank against a direct evaluation with numpy's FFT."""
+    through the reference-named functions, against the oracle's InitFBank and Wave2FBank."""
     import ctypes as C
     L = ma.compat_lib()
+    O = oracle.lib()
     W, sr, P, lo, hi, alpha, wl, wu = 400, 16000, 24, 60.0, 7600.0, 1.1, 300.0, 5000.0
     sp = 1e7 / sr
     info = L.InitFBank(W, sp, P, lo, hi, 0, 0, 1, alpha, wl, wu)
     assert L.MFCCCompatStatus() == 0 and info.fftN == 1024
-    N, nby2 = info.fftN, info.fftN // 2
-    fres = 1.0e7 / (sp * N * 700.0)
-    mel = lambda k: 1127 * np.log(1 + (k - 1) * fres)
-    mlo, mhi = 1127 * np.log(1 + lo / 700.0), 1127 * np.log(1 + hi / 700.0)
-    klo, khi = max(2, int(lo * sp * 1.0e-7 * N + 2.5)), min(nby2, int(hi * sp * 1.0e-7 * N + 0.5))
-    assert (info.klo, info.khi) == (klo, khi)
-
-    def warp(fcl, fcu, f, fmin, fmax, a):
-        scale = 1.0 / a
-        cu, cl = fcu * 2 / (1 + scale), fcl * 2 / (1 + scale)
-        au, al = (fmax - cu * scale) / (fmax - cu), (cl * scale - fmin) / (cl - fmin)
-        return au * (f - cu) + scale * cu if f > cu else (al * (f - fmin) + fmin if f < cl else scale * f)
-
-    fmin, fmax = 700.0 * (np.exp(mlo / 1127.0) - 1.0), 700.0 * (np.exp(mhi / 1127.0) - 1.0)
-    cf = []
-    for chan in range(1, P + 2):
-        c = chan / (P + 1) * (mhi - mlo) + mlo
-        c = 700 * (np.exp(c / 1127.0) - 1.0)
-        cf.append(1127.0 * np.log(1.0 + warp(wl, wu, c, fmin, fmax, alpha) / 700.0))
+    fb = oracle.OrcFBank()
+    assert O.orc_fbank_init_ex(C.byref(fb), W, sp, P, lo, hi, 0, 0, 1, alpha, wl, wu) == 0
+    nby2 = fb.fftN // 2
+    assert (info.fftN, info.klo, info.khi) == (fb.fftN, fb.klo, fb.khi)
     got_cf = np.array([info.cf[i + 1] for i in range(P + 1)])
-    assert np.max(np.abs(got_cf - np.array(cf))) < 1e-9
+    ref_cf = np.array([fb.cf[i] for i in range(P + 1)])
+    assert np.max(np.abs(got_cf - ref_cf)) < 1e-9
     lo_chan = np.array([info.loChan[i + 1] for i in range(nby2)])
     lo_wt = np.array([info.loWt[i + 1] for i in range(nby2)])
-    assert np.all(lo_chan[:klo - 1] == -1) and np.all(lo_chan[khi:] == -1)
-    assert np.all(np.diff(lo_chan[klo - 1:khi]) >= 0) and lo_chan[khi - 1] <= P
-    # magnitude mode without logs, against numpy
+    assert np.array_equal(lo_chan, np.array([fb.loChan[i] for i in range(nby2)]))
+    assert np.max(np.abs(lo_wt - np.array([fb.loWt[i] for i in range(nby2)]))) < 1e-12
+    # magnitude mode without logs
     rng = np.random.default_rng(3)
     frame = rng.standard_normal(W) * 2000.0
     s = L.MFCCCreateVector(W)
     for i, x in enumerate(frame):
         s[i + 1] = float(x)
-    fb = L.MFCCCreateVector(P)
+    fbv = L.MFCCCreateVector(P)
     te, te2 = C.c_double(), C.c_double()
-    L.Wave2FBank(s, fb, C.byref(te), C.byref(te2), info)
+    L.Wave2FBank(s, fbv, C.byref(te), C.byref(te2), info)
     assert L.MFCCCompatStatus() == 0
-    spec = np.fft.rfft(frame, N)
-    want = np.zeros(P + 2)
-    for k in range(klo, khi + 1):
-        ek = abs(spec[k - 1]) if k > 1 else abs(spec[0].real + spec[nby2].real)
-        b, t1 = lo_chan[k - 1], lo_wt[k - 1] * ek
-        if b > 0:
-            want[b] += t1
-        if b < P:
-            want[b + 1] += ek - t1
-    got = np.array([fb[i + 1] for i in range(P)])
-    assert np.max(np.abs(got - want[1:P + 1])) < 1e-8 * max(1.0, float(np.max(want)))
-    assert abs(te.value - float(np.sum(frame * frame))) < 1e-6 * te.value
+    dp = C.POINTER(C.c_double)
+    want = np.zeros(P)
+    x = np.zeros(fb.fftN)
+    rte, rte2 = C.c_double(), C.c_double()
+    fr = np.ascontiguousarray(frame)
+    O.orc_wave2fbank(fr.ctypes.data_as(dp), want.ctypes.data_as(dp), C.byref(rte), C.byref(rte2), C.byref(fb),
+                     x.ctypes.data_as(dp))
+    got = np.array([fbv[i + 1] for i in range(P)])
+    assert np.max(np.abs(got - want)) < 1e-8 * max(1.0, float(np.max(want)))
+    assert abs(te.value - rte.value) < 1e-9 * rte.value and abs(te2.value - rte2.value) < 1e-8 * rte2.value
     L.MFCCFreeVector(s)
-    L.MFCCFreeVector(fb)
+    L.MFCCFreeVector(fbv)
     L.MFCCFreeFBank(C.byref(info))
+    O.orc_fbank_free(C.byref(fb))
+
+
+_WARP = dict(warpAlpha=1.1, warpLowCut=300.0, warpUpCut=5000.0, lowpassfre=60.0, hipassfre=7600.0)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("opts", [dict(usePower=0), dict(doubleFFT=1), _WARP, dict(takeLogs=0),
+                                  dict(_WARP, usePower=0, doubleFFT=1, warpAlpha=0.9),
+                                  dict(normEnergy=1, energyFlag=1, regreOrder=3),
+                                  dict(normEnergy=1, energyFlag=1, regreOrder=2, znormFlag=1, doubleFFT=1)],
+                         ids=["magnitude", "double-fft", "warp", "no-logs", "all-three", "norm-energy", "norm-energy-znorm"])
+@pytest.mark.parametrize("name", ["c3", "c1a", "c2"])
+def test_options_the_reference_leaves_off_in_the_extraction_path(oracle, name, opts, precision):
+    """usePower = 0, takeLogs = 0, doubleFFT, the alpha warping (InitFBank arguments main.c:168
+    fixes, mfcc.c:55-56,83-92,154-157,171-176) and NormaliseLogEnergy (commented call main.c:255)
+    as options of the whole per-file path, against the oracle's extraction with the same options."""
+    kw = dict(CONFIGS[name], **opts)
+    f64 = precision == "f64"
+    if not f64 and not kw.get("takeLogs", 1):
+        pytest.skip("sums without logs span 1e15: compared in double only")
+    ch, bps = _layout(kw)
+    pcms = [_pcm(n, ch, bps, 11 + i, kw["sampleRate"]) for i, n in enumerate((kw["sampleRate"] // 2 + 57, 3 * kw["wlen"]))]
+    cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+    got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], ch, bps)
+    for g, p in zip(got, pcms):
+        ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), p, ch, bps)
+        _compare(g, ref, kw, f64)
 
 
 @pytest.mark.parametrize("name,frames,force_sweeps", [("c3", 1000, False), ("c3", 1100, False), ("c3", 97, True),
