@@ -1604,6 +1604,9 @@ int cached_context(const MFCCConfig &cfgIn, CtxRef *out)
     cfg.subBandEFlag = cfgIn.subBandEFlag, cfg.fftLength = cfgIn.fftLength, cfg.regreOrder = cfgIn.regreOrder;
     cfg.delwin = cfgIn.delwin, cfg.zeroMeanSigFlag = cfgIn.zeroMeanSigFlag, cfg.znormFlag = cfgIn.znormFlag;
     cfg.precision = cfgIn.precision;
+    cfg.usePower = cfgIn.usePower, cfg.takeLogs = cfgIn.takeLogs, cfg.doubleFFT = cfgIn.doubleFFT;
+    cfg.warpAlpha = cfgIn.warpAlpha, cfg.warpLowCut = cfgIn.warpLowCut, cfg.warpUpCut = cfgIn.warpUpCut;
+    cfg.normEnergy = cfgIn.normEnergy;
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess)
         return set_error("no HIP device available (the library has no CPU path)"), MFCC_E_DEVICE;

@@ -28,7 +28,9 @@ struct BankEntry {
 std::mutex g_mu;
 std::vector<BankEntry> g_banks;
 
-// grow-only device scratch shared by all calls (guarded by g_mu)
+// Grow-only device scratch and page-locked host staging shared by all calls, one private stream
+// (all guarded by g_mu).  They live on the GPU that was current at the library's first call; later
+// calls switch to that GPU for their duration, whatever the caller has made current since.
 struct Scratch {
     double *p = nullptr;
     size_t cap = 0;
@@ -42,6 +44,41 @@ struct Scratch {
         return p;
     }
 } g_scratch;
+struct Pinned {
+    double *p = nullptr;
+    size_t cap = 0;
+    double *ensure(size_t n)
+    {
+        if (n <= cap) return p;
+        if (p) (void)hipHostFree(p);
+        p = nullptr, cap = 0;
+        if (hipHostMalloc((void **)&p, n * sizeof(double), hipHostMallocDefault) != hipSuccess) return nullptr;
+        cap = n;
+        return p;
+    }
+} g_pinned;
+hipStream_t g_stream = nullptr;
+int g_device = -1;
+
+// Makes the library's GPU current for one call (g_mu held) and creates the stream on first use.
+struct DeviceCall {
+    int prev = -1;
+    bool ok = false;
+    DeviceCall()
+    {
+        if (hipGetDevice(&prev) != hipSuccess) return;
+        if (g_device < 0) g_device = prev;
+        if (prev != g_device && hipSetDevice(g_device) != hipSuccess) return;
+        if (!g_stream && hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking) != hipSuccess) return;
+        ok = true;
+    }
+    ~DeviceCall()
+    {
+        if (prev >= 0 && prev != g_device) (void)hipSetDevice(prev);
+    }
+};
+
+bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 int fail(int code, const char *what)
 {
@@ -159,26 +196,31 @@ extern "C" void Wave2FBank(Vector s, Vector fbank, double *te, double *te2, FBan
         return;
     }
     const int W = info.frameSize, P = info.numChans, N = info.fftN;
-    // scratch: frame | fbank | te | te2 | spectrum
-    double *d = g_scratch.ensure((size_t)W + P + 2 + N);
-    if (!d) {
+    DeviceCall dc;
+    // device scratch and host staging, both: frame | fbank | te | te2 | spectrum
+    const size_t total = (size_t)W + P + 2 + N;
+    double *d = dc.ok ? g_scratch.ensure(total) : nullptr;
+    double *h = d ? g_pinned.ensure(total) : nullptr;
+    if (!h) {
         hip_ok(hipErrorOutOfMemory, "Wave2FBank");
         return;
     }
     double *dFrame = d, *dFbank = d + W, *dTe = dFbank + P, *dTe2 = dTe + 1, *dSpec = dTe2 + 1;
-    if (!hip_ok(hipMemcpy(dFrame, s + 1, (size_t)W * sizeof(double), hipMemcpyHostToDevice), "Wave2FBank")) return;
+    memcpy(h, s + 1, (size_t)W * sizeof(double));
+    if (!hip_ok(hipMemcpyAsync(dFrame, h, (size_t)W * sizeof(double), hipMemcpyHostToDevice, g_stream), "Wave2FBank")) return;
     if (MFCCWave2FBankTablesDevice(MFCC_PREC_F64, dFrame, 1, W, N, info.klo, info.khi, P, be->dLoChan, be->dLoWt,
-                                   info.usePower, info.takeLogs, dFbank, dTe, dTe2, dSpec, nullptr)) {
+                                   info.usePower, info.takeLogs, dFbank, dTe, dTe2, dSpec, g_stream)) {
         fail(MFCC_E_DEVICE, "Wave2FBank");
         return;
     }
-    std::vector<double> host((size_t)P + 2 + N);
-    if (!hip_ok(hipMemcpy(host.data(), dFbank, host.size() * sizeof(double), hipMemcpyDeviceToHost), "Wave2FBank"))
+    double *out = h + W;
+    if (!hip_ok(hipMemcpyAsync(out, dFbank, ((size_t)P + 2 + N) * sizeof(double), hipMemcpyDeviceToHost, g_stream), "Wave2FBank") ||
+        !hip_ok(hipStreamSynchronize(g_stream), "Wave2FBank"))
         return;
-    memcpy(fbank + 1, host.data(), (size_t)P * sizeof(double));
-    if (te) *te = host[P];
-    if (te2) *te2 = host[P + 1];
-    if (info.x) memcpy(info.x + 1, host.data() + P + 2, (size_t)N * sizeof(double));
+    memcpy(fbank + 1, out, (size_t)P * sizeof(double));
+    if (te) *te = out[P];
+    if (te2) *te2 = out[P + 1];
+    if (info.x) memcpy(info.x + 1, out + P + 2, (size_t)N * sizeof(double));
 }
 
 static void cepstra(Vector fbank, Vector c, int n, double *c0)
@@ -190,20 +232,25 @@ static void cepstra(Vector fbank, Vector c, int n, double *c0)
         return;
     }
     std::lock_guard<std::mutex> lock(g_mu);
-    double *d = g_scratch.ensure((size_t)P + n + 1);
-    if (!d) {
+    DeviceCall dc;
+    const size_t total = (size_t)P + n + 1;
+    double *d = dc.ok ? g_scratch.ensure(total) : nullptr;
+    double *h = d ? g_pinned.ensure(total) : nullptr;
+    if (!h) {
         hip_ok(hipErrorOutOfMemory, "FBank2MFCC");
         return;
     }
-    if (!hip_ok(hipMemcpy(d, fbank + 1, (size_t)P * sizeof(double), hipMemcpyHostToDevice), "FBank2MFCC")) return;
-    if (MFCCFBank2MFCCDirectDevice(MFCC_PREC_F64, d, 1, P, n, d + P, c0 ? d + P + n : nullptr, nullptr)) {
+    memcpy(h, fbank + 1, (size_t)P * sizeof(double));
+    if (!hip_ok(hipMemcpyAsync(d, h, (size_t)P * sizeof(double), hipMemcpyHostToDevice, g_stream), "FBank2MFCC")) return;
+    if (MFCCFBank2MFCCDirectDevice(MFCC_PREC_F64, d, 1, P, n, d + P, c0 ? d + P + n : nullptr, g_stream)) {
         fail(MFCC_E_DEVICE, "FBank2MFCC");
         return;
     }
-    std::vector<double> host((size_t)n + 1);
-    if (!hip_ok(hipMemcpy(host.data(), d + P, host.size() * sizeof(double), hipMemcpyDeviceToHost), "FBank2MFCC")) return;
-    if (c && n > 0) memcpy(c + 1, host.data(), (size_t)n * sizeof(double));
-    if (c0) *c0 = host[n];
+    if (!hip_ok(hipMemcpyAsync(h + P, d + P, ((size_t)n + 1) * sizeof(double), hipMemcpyDeviceToHost, g_stream), "FBank2MFCC") ||
+        !hip_ok(hipStreamSynchronize(g_stream), "FBank2MFCC"))
+        return;
+    if (c && n > 0) memcpy(c + 1, h + P, (size_t)n * sizeof(double));
+    if (c0) *c0 = h[P + n];
 }
 
 extern "C" void FBank2MFCC(Vector fbank, Vector c, int n) { cepstra(fbank, c, n, nullptr); }
@@ -219,19 +266,31 @@ static void transform(Vector s, int invert, bool real)
 {
     g_status = 0;
     const int n = MFCCVectorSize(s);
+    const char *what = real ? "Realft" : "FFT";
+    if (!is_pow2(n) || n < (real ? 4 : 2)) { // (the reference's loops assume it: mfcc.c:216-229,267)
+        g_status = MFCC_E_ARG;
+        fprintf(stderr, "%s: the vector size %d is not a power of two >= %d\n", what, n, real ? 4 : 2);
+        return;
+    }
     std::lock_guard<std::mutex> lock(g_mu);
-    double *d = g_scratch.ensure((size_t)(n > 0 ? n : 1));
-    if (!d) {
-        hip_ok(hipErrorOutOfMemory, real ? "Realft" : "FFT");
+    DeviceCall dc;
+    double *d = dc.ok ? g_scratch.ensure((size_t)n) : nullptr;
+    double *h = d ? g_pinned.ensure((size_t)n) : nullptr;
+    if (!h) {
+        hip_ok(hipErrorOutOfMemory, what);
         return;
     }
-    if (!hip_ok(hipMemcpy(d, s + 1, (size_t)n * sizeof(double), hipMemcpyHostToDevice), real ? "Realft" : "FFT")) return;
-    const int rc = real ? MFCCRealftDevice(MFCC_PREC_F64, d, 1, n, nullptr) : MFCCFFTDevice(MFCC_PREC_F64, d, 1, n, invert, nullptr);
+    memcpy(h, s + 1, (size_t)n * sizeof(double));
+    if (!hip_ok(hipMemcpyAsync(d, h, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_stream), what)) return;
+    const int rc = real ? MFCCRealftDevice(MFCC_PREC_F64, d, 1, n, g_stream) : MFCCFFTDevice(MFCC_PREC_F64, d, 1, n, invert, g_stream);
     if (rc) {
-        fail(rc, real ? "Realft" : "FFT");
+        fail(rc, what);
         return;
     }
-    hip_ok(hipMemcpy(s + 1, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost), real ? "Realft" : "FFT");
+    if (!hip_ok(hipMemcpyAsync(h, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g_stream), what) ||
+        !hip_ok(hipStreamSynchronize(g_stream), what))
+        return;
+    memcpy(s + 1, h, (size_t)n * sizeof(double));
 }
 
 extern "C" void FFT(Vector s, int invert) { transform(s, invert, false); }
