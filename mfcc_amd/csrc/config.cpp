@@ -125,6 +125,9 @@ int validate_config(const MFCCConfig &c)
         return set_error("normEnergy needs a column behind the coefficients (MFCC0thFlag or energyFlag)"), MFCC_E_CONFIG;
     if (c.subBandEFlag > fftN / 2 || c.fftLength > fftN / 2)
         return set_error("subBandEFlag / fftLength exceed fftN/2 = %d", fftN / 2), MFCC_E_CONFIG;
+    if (c.znormFlag && MFCCStep(&c) > kMaxZnormStep) // the z-norm kernel keeps a row's means and deviations in LDS
+        return set_error("znormFlag supports rows of at most %d columns (this option set has %d)", kMaxZnormStep, MFCCStep(&c)),
+               MFCC_E_CONFIG;
     if (c.precision != MFCC_PREC_F32 && c.precision != MFCC_PREC_F64)
         return set_error("precision must be 0 (f32) or 1 (f64)"), MFCC_E_CONFIG;
     return MFCC_OK;

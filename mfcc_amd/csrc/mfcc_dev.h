@@ -7,6 +7,7 @@ namespace mfcc {
 
 constexpr int kBlock = 256;       // threads per workgroup of every kernel (4 waves of 64)
 constexpr int kMaxLog2Nc = 13;    // fftN <= 16384
+constexpr int kMaxZnormStep = 8192; // columns per row the z-norm kernel holds statistics for (16 bytes each in LDS)
 constexpr int kStatRows = 256;    // rows per workgroup of the z-norm statistics kernels
 constexpr int kRegRows = 256;     // rows per workgroup of the regression / fused delta kernels
 constexpr int kMelSteps = 32;     // most bins one block of the matrix-core mel filterbank walks

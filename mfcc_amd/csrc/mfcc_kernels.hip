@@ -1111,16 +1111,16 @@ __global__ __launch_bounds__(kBlock) void k_uttsums(const unsigned char *pcm, co
                                                     int channels, int bps,
                                                     unsigned long long *sums2)
 {
-    const UttDesc ud = utts[blockIdx.y];
+    const UttDesc ud = utts[blockIdx.x]; // (the utterance in x: y is limited to 65535 workgroups)
     const int bpi = channels * bps;
     long long sL = 0, sR = 0;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < ud.numInstants;
-         i += (long long)gridDim.x * kBlock) {
+    for (long long i = (long long)blockIdx.y * kBlock + threadIdx.x; i < ud.numInstants;
+         i += (long long)gridDim.y * kBlock) {
         const unsigned char *p = pcm + ud.byteOff + i * bpi;
         sL += gmem_sample(p, bps);
         if (channels == 2) sR += gmem_sample(p + bps, bps);
     }
-    block_add4(sL, sR, sums2 + 4 * blockIdx.y);
+    block_add4(sL, sR, sums2 + 4 * blockIdx.x);
 }
 
 __global__ void k_uttmeans(UttDesc *utts, int numUtts, const unsigned long long *sums2)
@@ -1345,6 +1345,11 @@ int launch_normalize(int precision, const void *args, int numChunks, bool shardS
     const size_t lds = 2 * sizeof(double) *
                        (size_t)(precision == 1 ? static_cast<const StatArgs<double> *>(args)->step
                                                : static_cast<const StatArgs<float> *>(args)->step);
+    if (lds > 48 * 1024) { // rows of more than 3072 columns (validate_config stops at kMaxZnormStep)
+        const void *k = precision == 1 ? (shardSums ? (const void *)&k_normalize<double, true> : (const void *)&k_normalize<double, false>)
+                                       : (shardSums ? (const void *)&k_normalize<float, true> : (const void *)&k_normalize<float, false>);
+        if (hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) return (int)e;
+    }
     if (precision == 1) {
         const StatArgs<double> &a = *static_cast<const StatArgs<double> *>(args);
         if (shardSums)
@@ -1383,7 +1388,7 @@ int launch_uttmeans(const unsigned char *pcm, UttDesc *utts, int numUtts, int ch
     if (numUtts <= 0) return 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int bx = numUtts >= 2048 ? 1 : (numUtts >= 64 ? 8 : 256);
-    hipLaunchKernelGGL(k_uttsums, dim3(bx, numUtts), dim3(kBlock), 0, st, pcm, utts, channels, bps,
+    hipLaunchKernelGGL(k_uttsums, dim3(numUtts, bx), dim3(kBlock), 0, st, pcm, utts, channels, bps,
                        sums2);
     int rc = (int)hipGetLastError();
     if (rc) return rc;

@@ -16,6 +16,7 @@ import pytest
 
 import mfcc_amd as ma
 from mfcc_amd.presets import CONFIGS
+import util
 from util import assert_static_close, column_kinds, run_product_batch
 
 pytestmark = pytest.mark.gpu
@@ -699,6 +700,38 @@ def test_options_the_reference_leaves_off_in_the_extraction_path(oracle, name, o
     for g, p in zip(got, pcms):
         ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), p, ch, bps)
         _compare(g, ref, kw, f64)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("name", ["c3", "c1a"])
+def test_an_utterance_gives_the_same_bits_alone_and_beside_a_long_neighbour(name, precision):
+    """The delta / z-norm kernel is chosen from the longest utterance of a batch (whole-utterance
+    kernel in registers or in two sweeps, or the row-block kernels): one file must come out
+    bit-identical whatever its batch neighbours are (MFCCWapperList batches, MFCCWapper does not).
+    One exception is measured here instead: double-precision z-normalised rows, whose column sums
+    the variants add in different orders (and E[x^2] - mean^2 amplifies the last bits), agree to 1e-9
+    of the column's largest magnitude."""
+    kw = CONFIGS[name]
+    ch, bps = _layout(kw)
+    sr = kw["sampleRate"]
+    short = _pcm(sr // 2 + 77, ch, bps, 31, sr)
+    mid = _pcm(3 * sr, ch, bps, 32, sr)
+    long_ = _pcm(40 * sr if name == "c3" else 12 * sr, ch, bps, 33, sr)
+    cfg = ma.make_config(precision=ma.PREC_F64 if precision == "f64" else ma.PREC_F32, **kw)
+    alone = run_product_batch(ma, cfg, [short.tobytes()], ch, bps)[0]
+    alone_mid = run_product_batch(ma, cfg, [mid.tobytes()], ch, bps)[0]
+    def same(a, b):
+        if precision == "f64" and kw.get("znormFlag", 0):
+            scale = np.maximum(np.nanmax(np.abs(b), axis=0, keepdims=True), 1.0)
+            err = float(np.nanmax(np.abs(a - b) / scale))
+            util._note("f64 z-norm, alone vs batch", err, 1e-9)
+            return np.array_equal(np.isnan(a), np.isnan(b)) and err < 1e-9
+        return np.array_equal(a, b, equal_nan=True)
+
+    for batch in ([short, mid], [short, mid, long_]):
+        got = run_product_batch(ma, cfg, [b.tobytes() for b in batch], ch, bps)
+        assert same(got[0], alone)
+        assert same(got[1], alone_mid)
 
 
 @pytest.mark.parametrize("name,frames,force_sweeps", [("c3", 1000, False), ("c3", 1100, False), ("c3", 97, True),
