@@ -337,15 +337,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
             STAMP(3);
 
             // ---- real-FFT split and power (mfcc.c:274-290, ek of mfcc.c:153-155): Z[256 - k] for
-            //      k = l + 16 q is register 15 - q of lane 16 - l (own register 16 - q in lane 0)
+            //      k = l + 16 q is register 15 - q of lane 16 - l (register 16 - q of lane 0 itself)
             T pa[PPL / 2], pb[PPL / 2];
             if constexpr (SWL) lds_read_strided<PPL / 2, 128>(swreg, swl + l);
+            {
+                // the upper half of the lane's points goes through the (free) work area, complex
+                // index = bin; the lane reads back Z[256 - l - 16 q], q = 7 .. 0 (lane 0, q = 0: one
+                // point past the bins, unused).  The power values below use the area's first half.
 #pragma unroll
-            for (int q = 0; q < PPL / 2; ++q) {
-                const cpx<T> hi = v[PPL - 1 - q], own = v[(PPL - q) & (PPL - 1)];
-                const float px = row_negated_lane(hi.x), py = row_negated_lane(hi.y);
-                const cpx<T> zb = {l == 0 ? own.x : px, l == 0 ? own.y : py};
-                split_power<T>(v[q], zb, swreg[q], pa[q], pb[q]);
+                for (int r = PPL / 2; r < PPL; ++r) Z[l + G * r] = v[r];
+                team_sync<TEAM>();
+                cpx<T> rev[PPL / 2];
+                lds_read_strided<PPL / 2, G * 8>(rev, &Z[NC - l - G * (PPL / 2 - 1)]);
+#pragma unroll
+                for (int q = 0; q < PPL / 2; ++q) split_power<T>(v[q], rev[PPL / 2 - 1 - q], swreg[q], pa[q], pb[q]);
             }
             {
                 // bin 0 packs Re + Im of Z[0] (mfcc.c:288-290); bin 128 is |Z[128]|^2; lane 0 holds both
