@@ -609,12 +609,17 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                 const int4 sg = rd == 0 ? part0 : part1;
                 cpx<T> acc = {0, 0};
                 if (rd < a.maxSeg) {
-                    for (int h = 0; h < a.melPieces; ++h) { // melPieces x 8 bins per part at most (reads past the part stay inside the work area and are dropped)
+                    for (int h = 0; h < a.melPieces; ++h) { // melPieces x 8 bins per part at most
                         cpx<T> vq[8];
                         lds_read_strided<8, 8>(vq, &AB[sg.x + 8 * h]);
+                        // reads past the part stay inside the work area (finite values of this round)
+                        // and enter with the factor clamp(left - i) = 0; the others with 1
+                        const float left = (float)(sg.y - sg.x - 8 * h);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            if (sg.x + 8 * h + i < sg.y) acc = cadd(acc, vq[i]);
+                        for (int i = 0; i < 8; ++i) {
+                            const float m = __builtin_amdgcn_fmed3f(left - (float)i, 0.0f, 1.0f);
+                            acc = cfma_r(vq[i], m, acc);
+                        }
                     }
                 }
                 ps[rd] = acc;
@@ -640,10 +645,11 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                     pt[j] = Pw[chanParts.z + j];
                 }
                 T mu = 0, mt = 0;
+                const float nu = (float)chanParts.y, nt = (float)chanParts.w;
 #pragma unroll
-                for (int j = 0; j < 10; ++j) {
-                    mu += j < chanParts.y ? pu[j] : (T)0;
-                    mt += j < chanParts.w ? pt[j] : (T)0;
+                for (int j = 0; j < 10; ++j) { // (slots past the segment's parts: finite values, factor 0)
+                    mu = __builtin_fmaf(pu[j], __builtin_amdgcn_fmed3f(nu - (float)j, 0.0f, 1.0f), mu);
+                    mt = __builtin_fmaf(pt[j], __builtin_amdgcn_fmed3f(nt - (float)j, 0.0f, 1.0f), mt);
                 }
                 const T m = mu + mt;
                 lv = tlog<T>(m < (T)1 ? (T)1 : m);
