@@ -82,7 +82,7 @@ __device__ __forceinline__ int sample24(const unsigned (&d)[NW])
 // being formed in double with separately rounded product and difference as the reference's code
 // does, so that the sign of a near-cancelling sample is the reference's.
 template <int NZ, bool ZC, int ROW, bool EXACT>
-__device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, const unsigned *raw, int l,
+__device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, const unsigned *rawLane, int l,
                                             const cpx<float> (&wreg)[NZ], double preK, float kf, float zcThr, bool firstTile, int wlen)
 {
     constexpr int G = kWideG;
@@ -92,9 +92,11 @@ __device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, 
     unsigned own[NZ][5];
 #pragma unroll
     for (int r = 0; r < NZ; ++r) {
-        const unsigned *src = raw + 3 * (l + G * r);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) own[r][i] = src[i];
+        const unsigned *src = rawLane + 3 * G * r; // (rawLane: the lane's first pair, raw + 3 l)
+        // (one 16-byte and one 4-byte read at a dword-aligned address: immediate offsets, no address arithmetic)
+        const u4u q = *reinterpret_cast<const u4u *>(src);
+        own[r][0] = q.x, own[r][1] = q.y, own[r][2] = q.z, own[r][3] = q.w;
+        own[r][4] = src[4];
     }
 #pragma unroll
     for (int r = NZ - 1; r >= 0; --r) {
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     T *dctL = reinterpret_cast<T *>(smem);
     unsigned char *region = smem + ((size_t)a.tabElems + (size_t)wave * a.teamElems) * sizeof(T);
     unsigned *raw = reinterpret_cast<unsigned *>(region);
+    const unsigned *rawLane = raw + 3 * tt0; // the lane's first sample pair (plain lane index: kept over the rounds)
     T *Zt = reinterpret_cast<T *>(region) + a.rowPitch; // (rowPitch: elements reserved for the raw bytes)
     cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
     cpx<T> *AB = Z;                                               // per bin (loWt p, p - loWt p)
@@ -415,19 +418,19 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             int zc = 0;
             bool unsure;
             switch (vv) { // (the same for every lane)
-            case 0: unsure = wide_expand<NZ, ZC, 0, false>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-            case 1: unsure = wide_expand<NZ, ZC, 1, false>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-            case 2: unsure = wide_expand<NZ, ZC, 2, false>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-            default: unsure = wide_expand<NZ, ZC, 3, false>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+            case 0: unsure = wide_expand<NZ, ZC, 0, false>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+            case 1: unsure = wide_expand<NZ, ZC, 1, false>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+            case 2: unsure = wide_expand<NZ, ZC, 2, false>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+            default: unsure = wide_expand<NZ, ZC, 3, false>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
             }
             if constexpr (ZC) {
                 if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) {
                     zc = 0;
                     switch (vv) {
-                    case 0: wide_expand<NZ, ZC, 0, true>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-                    case 1: wide_expand<NZ, ZC, 1, true>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-                    case 2: wide_expand<NZ, ZC, 2, true>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-                    default: wide_expand<NZ, ZC, 3, true>(v, zc, raw, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+                    case 0: wide_expand<NZ, ZC, 0, true>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+                    case 1: wide_expand<NZ, ZC, 1, true>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+                    case 2: wide_expand<NZ, ZC, 2, true>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+                    default: wide_expand<NZ, ZC, 3, true>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
                     }
                 }
             }
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             STAMP(2);
 
             // ---- 1024-point complex FFT of z[n] = x[2n] + i x[2n+1] (Realft mfcc.c:262-270)
-            wide_fft(v, Z, l, twB, twC);
+            wide_fft(v, Z, tt0, twB, twC); // (plain lane index: the stage addresses stay in registers over the rounds)
             STAMP(3);
 
             // ---- real-FFT split and power (mfcc.c:274-290, ek of mfcc.c:153-155)
@@ -459,8 +462,8 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             {
                 constexpr int QS = (G + G / 16) * 8;
                 cpx<T> zas[NPAIR], rev[NPAIR];
-                lds_read_strided<NPAIR, QS>(zas, &Z[zpad(l)]);
-                lds_read_strided<NPAIR, QS>(rev, &Z[zpad(NC - l - G * (NPAIR - 1))]); // (lane 0: one point past the area, unused)
+                lds_read_strided<NPAIR, QS>(zas, &Z[zpad(tt0)]);
+                lds_read_strided<NPAIR, QS>(rev, &Z[zpad(NC - tt0 - G * (NPAIR - 1))]); // (lane 0: one point past the area, unused)
 #pragma unroll
                 for (int q = 0; q < NPAIR; ++q) split_power<T>(zas[q], rev[NPAIR - 1 - q], swreg[q], pa[q], pb[q]);
                 // bin 0 packs Re + Im of Z[0] (mfcc.c:288-290); bin nc/2 is |Z[nc/2]|^2
