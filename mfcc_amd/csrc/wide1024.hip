@@ -443,14 +443,15 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             }
             STAMP(1);
             cpx<T> twB[15], twC[12], swreg[NPAIR];
+            const unsigned lu = (unsigned)tt0; // (one unsigned lane offset under uniform row pointers: scalar address arithmetic)
 #pragma unroll
-            for (int r = 1; r < 16; ++r) twB[r - 1] = twt[(r - 1) * 16 + (l & 15)]; // sub-transform size 16: [r-1][l mod 16]
+            for (int r = 1; r < 16; ++r) twB[r - 1] = (twt + (r - 1) * 16)[lu & 15u]; // sub-transform size 16: [r-1][l mod 16]
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 1; r < 4; ++r) twC[b * 3 + r - 1] = twt[15 * 16 + (r - 1) * 256 + 64 * b + l]; // size 256: [r-1][l + 64 b]
+                for (int r = 1; r < 4; ++r) twC[b * 3 + r - 1] = (twt + (15 * 16 + (r - 1) * 256 + 64 * b))[lu]; // size 256: [r-1][l + 64 b]
 #pragma unroll
-            for (int q = 0; q < NPAIR; ++q) swreg[q] = splitTab[G * q + l];
+            for (int q = 0; q < NPAIR; ++q) swreg[q] = (splitTab + G * q)[lu];
             STAMP(2);
 
             // ---- 1024-point complex FFT of z[n] = x[2n] + i x[2n+1] (Realft mfcc.c:262-270)
@@ -490,8 +491,9 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             T lwreg[2 * NPAIR]; // weights of bins l + 64 q and nc - l - 64 q (lane 0, q = 0: bin nc / 2)
 #pragma unroll
             for (int q = 0; q < NPAIR; ++q) {
-                lwreg[2 * q] = a.loWt[G * q + l];
-                lwreg[2 * q + 1] = a.loWt[(q == 0 && l == 0) ? NC / 2 : NC - G * q - l];
+                // (uniform row pointers indexed by one unsigned lane offset: scalar address arithmetic)
+                lwreg[2 * q] = (a.loWt + G * q)[lu];
+                lwreg[2 * q + 1] = q == 0 ? a.loWt[lu == 0u ? (unsigned)(NC / 2) : (unsigned)NC - lu] : (a.loWt + (NC - G * q - 63))[63u - lu];
             }
             STAMP(4);
 
