@@ -90,6 +90,7 @@ struct MFCCPlan {
     double *dBlockPartial = nullptr;
     // whole-utterance finishing pass (deltas + z-norm from compact static rows), see finish.hip
     bool uttFinish = false;
+    int regRows = kRegRows; // rows per block of the regression / fused delta kernels
     void *dStatics = nullptr; // totalRows x vSize
     int finSubRows = 0, finStaticElems = 0, finRedOffset = 0, finRegRows = 0;
     size_t finLds = 0;
@@ -707,6 +708,17 @@ static int finish_plan(MFCCPlan *p)
     const Tuning tune = tuning();
     int rc = choose_tile(p);
     if (rc) return rc;
+    // Rows per block of the regression / fused delta kernels: 256, or fewer (down to 32) while the
+    // plan has fewer blocks than two per CU, so that one file alone still spreads over the GPU.  (Every
+    // LDS sub-tile of a block carries its own halo rows, so smaller blocks cost no extra reads.)
+    {
+        DEVICE_SCOPE(c->device);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0)
+            p->numCus = cus;
+        p->regRows = kRegRows;
+        while (p->regRows > 32 && p->totalRows / p->regRows < 2 * (int64_t)p->numCus) p->regRows /= 2;
+    }
     std::vector<int32_t> tileUtt, chunkUtt, regUtt;
     std::vector<TileDesc> tileDesc;
     int64_t tiles = 0, chunks = 0, regBlocks = 0;
@@ -716,7 +728,7 @@ static int finish_plan(MFCCPlan *p)
         UttDesc &d = p->utts[u];
         const int nt = (d.numFrames + p->framesPerTile - 1) / p->framesPerTile;
         const int ncb = (d.ownCount + kStatRows - 1) / kStatRows;
-        const int nrb = (d.numFrames + kRegRows - 1) / kRegRows;
+        const int nrb = (d.numFrames + p->regRows - 1) / p->regRows;
         if (tiles + nt > 0x7fffffffLL || chunks + ncb > 0x7fffffffLL)
             return set_error("batch too large: more than 2^31 tiles"), MFCC_E_ARG;
         d.regBegin = (int32_t)regBlocks;
@@ -766,7 +778,7 @@ static int finish_plan(MFCCPlan *p)
             tileUtt.push_back(u);
         }
         chunkUtt.insert(chunkUtt.end(), (size_t)((d.ownCount + kStatRows - 1) / kStatRows), u);
-        regUtt.insert(regUtt.end(), (size_t)((d.numFrames + kRegRows - 1) / kRegRows), u);
+        regUtt.insert(regUtt.end(), (size_t)((d.numFrames + p->regRows - 1) / p->regRows), u);
     }
     p->planEnd = planEnd;
     p->numRegBlocks = (int)regBlocks;
@@ -1257,6 +1269,7 @@ static int run_regress(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
         a.srcCol = (order - 2) * c->vSize;
         a.dstCol = (order - 1) * c->vSize;
         a.delwin = c->cfg.delwin;
+        a.regRows = p->regRows;
         a.sigmaT2 = sigmaT2;
         a.invSigmaT2 = (T)(1.0 / sigmaT2);
         const int rc = launch_regress(c->cfg.precision, &a, p->numRegBlocks, stream);
@@ -1281,6 +1294,7 @@ static int run_delta(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
     a.step = c->step;
     a.delwin = c->cfg.delwin;
     a.subRows = p->deltaSubRows;
+    a.regRows = p->regRows;
     a.redOffset = p->deltaRedOffset;
     a.sigmaT2 = 2.0 * sigmaT2;
     a.partial = p->dBlockPartial;
@@ -1408,7 +1422,7 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
         if (!byBlock && (rc = run_colstats(c, p, outDev, stream))) return rc;
         StatArgs<float> fa = stat_args<float>(c, p, nullptr);
         if (byBlock) fa.partial = p->dBlockPartial;
-        const int e = launch_colfinal(fa, p->numUtts, byBlock, stream);
+        const int e = launch_colfinal(fa, p->numUtts, byBlock ? p->regRows : 0, stream);
         if (e) return set_error("z-norm finalise kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
         if ((rc = run_normalize(c, p, outDev, false, nullptr, stream))) return rc;
     }

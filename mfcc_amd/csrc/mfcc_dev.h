@@ -9,7 +9,7 @@ constexpr int kBlock = 256;       // threads per workgroup of every kernel (4 wa
 constexpr int kMaxLog2Nc = 13;    // fftN <= 16384
 constexpr int kMaxZnormStep = 8192; // columns per row the z-norm kernel holds statistics for (16 bytes each in LDS)
 constexpr int kStatRows = 256;    // rows per workgroup of the z-norm statistics kernels
-constexpr int kRegRows = 256;     // rows per workgroup of the regression / fused delta kernels
+constexpr int kRegRows = 256;     // rows per workgroup of the regression / fused delta kernels (fewer in small batches: MFCCPlan::regRows)
 constexpr int kMelSteps = 32;     // most bins one block of the matrix-core mel filterbank walks
 
 // One utterance (or one rank's shard of a long recording) as the kernels see it.
@@ -98,9 +98,10 @@ template <typename T>
 struct RegressArgs {
     T *data;
     const UttDesc *utts;
-    const int32_t *blockUtt; // utterance of each kRegRows-row block
+    const int32_t *blockUtt; // utterance of each block of regRows rows
     int numBlocks;
     int vSize, step, srcCol, dstCol, delwin;
+    int regRows;             // rows per block
     T invSigmaT2;
     double sigmaT2;
 };
@@ -110,10 +111,11 @@ template <typename T>
 struct DeltaArgs {
     T *data;
     const UttDesc *utts;
-    const int32_t *blockUtt; // utterance of each kRegRows-row block
+    const int32_t *blockUtt; // utterance of each block of regRows rows
     int numBlocks;
     int vSize, step, delwin;
     int subRows;             // rows per LDS sub-tile
+    int regRows;             // rows per block (a multiple of subRows)
     int redOffset;           // byte offset of the 2 * kBlock doubles of reduction scratch in LDS
     double sigmaT2;
     double *partial;         // numBlocks x 2*step: per-block column sums and sums of squares, or NULL
@@ -168,7 +170,7 @@ int front_waves_limit(int precision, int log2nc, int pplog); // waves per SIMD t
 int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, int mode, size_t ldsBytes);
 int launch_regress(int precision, const void *args, int numBlocks, void *stream);
 int launch_colstats(int precision, const void *args, int numChunks, void *stream);
-int launch_colfinal(const StatArgs<float> &a, int numUtts, bool byBlock, void *stream);
+int launch_colfinal(const StatArgs<float> &a, int numUtts, int blockRows, void *stream); // blockRows > 0: partial sums per block of that many rows
 int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, double *sumsOut, void *stream);
 int launch_delta(int precision, const void *args, int orders, size_t ldsBytes, void *stream); // -2: no such variant
 int launch_utt_finish(int precision, const void *args, int orders, int numUtts, size_t ldsBytes, void *stream);

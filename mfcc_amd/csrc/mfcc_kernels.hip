@@ -769,8 +769,8 @@ __global__ __launch_bounds__(kBlock) void k_regress(const RegressArgs<T> a)
     for (int blk = blockIdx.x; blk < a.numBlocks; blk += gridDim.x) {
         const int u = a.blockUtt[blk];
         const UttDesc ud = a.utts[u];
-        const int f0 = (blk - ud.regBegin) * kRegRows;
-        const int nf = min(kRegRows, ud.numFrames - f0);
+        const int f0 = (blk - ud.regBegin) * a.regRows;
+        const int nf = min(a.regRows, ud.numFrames - f0);
         const int n = ud.numFrames;
         T *base = a.data + ud.outRow * a.step;
         for (int i = threadIdx.x; i < nf * a.vSize; i += kBlock) {
@@ -809,8 +809,8 @@ __global__ __launch_bounds__(kBlock) void k_delta(const DeltaArgs<T> a)
     const int u = a.blockUtt[blk];
     const UttDesc ud = a.utts[u];
     const int n = ud.numFrames;
-    const int r0 = (blk - ud.regBegin) * kRegRows;
-    const int nr = min(kRegRows, n - r0);
+    const int r0 = (blk - ud.regBegin) * a.regRows;
+    const int nr = min(a.regRows, n - r0);
     T *base = a.data + ud.outRow * a.step;
     const int tid = threadIdx.x;
     // statistics: lane (rl, col) sums rows rl, rl + rowLanes, ... of every sub-tile
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(const UttDesc *utts, const 
     UttDesc ud = utts[u];
     int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
     if (byBlock) {
-        nchunk = (ud.numFrames + kRegRows - 1) / kRegRows;
+        nchunk = (ud.numFrames + byBlock - 1) / byBlock; // (byBlock: rows per block)
         ud.statBegin = ud.regBegin;
     }
     // blockIdx.y owns kFinalCols columns: kBlock / kFinalCols row groups
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(kBlock) void k_shardfinal(const UttDesc *utts, cons
     UttDesc ud = utts[0];
     int nchunk = (ud.ownCount + kStatRows - 1) / kStatRows;
     if (byBlock) {
-        nchunk = (ud.numFrames + kRegRows - 1) / kRegRows;
+        nchunk = (ud.numFrames + byBlock - 1) / byBlock; // (byBlock: rows per block)
         ud.statBegin = ud.regBegin;
     }
     {
@@ -1291,11 +1291,11 @@ int launch_colstats(int precision, const void *args, int numChunks, void *stream
     return (int)hipGetLastError();
 }
 
-int launch_colfinal(const StatArgs<float> &a, int numUtts, bool byBlock, void *stream)
+int launch_colfinal(const StatArgs<float> &a, int numUtts, int blockRows, void *stream)
 {
     if (numUtts <= 0) return 0;
     hipLaunchKernelGGL(k_colfinal, dim3(numUtts, (a.step + kFinalCols - 1) / kFinalCols), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       a.utts, a.partial, a.stats, a.step, byBlock ? 1 : 0);
+                       a.utts, a.partial, a.stats, a.step, blockRows);
     return (int)hipGetLastError();
 }
 
@@ -1303,7 +1303,7 @@ int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, dou
 {
     (void)numChunks;
     hipLaunchKernelGGL(k_shardfinal, dim3(1, (2 * a.step + kFinalCols - 1) / kFinalCols), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       a.utts, a.partial, sumsOut, a.step, byBlock ? 1 : 0);
+                       a.utts, a.partial, sumsOut, a.step, byBlock ? kRegRows : 0);
     return (int)hipGetLastError();
 }
 
