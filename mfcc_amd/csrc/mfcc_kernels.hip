@@ -824,10 +824,24 @@ __global__ __launch_bounds__(kBlock) void k_delta(const DeltaArgs<T> a)
     for (int s = r0; s < r0 + nr; s += SR) {
         const int rows = min(SR, r0 + nr - s);
         // static rows s - H .. s + rows + H - 1, clamped
-        for (int i = tid; i < (rows + 2 * H) * W; i += kBlock) {
-            const int p = i / W, c = i - p * W;
-            const int t = min(max(s - H + p, 0), n - 1);
-            bufA[i] = base[(long long)t * a.step + c];
+        // (eight loads in flight per lane before the first is stored: the loop is bound by the
+        // latency of these reads, not by their volume)
+        for (int i0 = tid; i0 < (rows + 2 * H) * W; i0 += 8 * kBlock) {
+            T tmp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * kBlock;
+                if (i < (rows + 2 * H) * W) {
+                    const int p = i / W, c = i - p * W;
+                    const int t = min(max(s - H + p, 0), n - 1);
+                    tmp[j] = base[(long long)t * a.step + c];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * kBlock;
+                if (i < (rows + 2 * H) * W) bufA[i] = tmp[j];
+            }
         }
         __syncthreads();
         if (stats && rl < rowLanes)
@@ -844,17 +858,59 @@ __global__ __launch_bounds__(kBlock) void k_delta(const DeltaArgs<T> a)
 #pragma unroll
         for (int o = 1; o < ORD; ++o) {
             const int hn = hp - a.delwin;
-            for (int i = tid; i < (rows + 2 * hn) * W; i += kBlock) {
-                const int p = i / W, c = i - p * W;
-                const int t = min(max(s - hn + p, 0), n - 1); // the row whose delta this entry holds
-                const int q = t - (s - hp);                    // its entry in prev
-                T sum = 0;
-                for (int tau = 1; tau <= a.delwin; ++tau)
-                    sum += (T)tau * (prev[(q + tau) * W + c] - prev[(q - tau) * W + c]);
-                const T d = (T)((double)sum / a.sigmaT2);
-                next[i] = d;
-                const int row = s - hn + p;
-                if (row >= s && row < s + rows) base[(long long)row * a.step + o * W + c] = d;
+            // (T)((double)sum / sigmaT2): in single precision the correctly rounded float quotient is
+            // the same number (sigmaT2 is a small integer, double carries more than 2 x 24 + 2 bits)
+            const float sigmaF = (float)a.sigmaT2;
+            auto quotient = [&](T sum) -> T {
+                if constexpr (sizeof(T) == 4)
+                    return sum / sigmaF;
+                else
+                    return (T)((double)sum / a.sigmaT2);
+            };
+            if ((W & 1) == 0 && (reinterpret_cast<unsigned long long>(a.data) & (2 * sizeof(T) - 1)) == 0) {
+                // even row width (and an output matrix aligned for two elements): a lane forms two neighbouring columns at once (8- or 16-byte LDS
+                // accesses, packed arithmetic); lane (rlp, cp) takes column pair cp of the entries
+                // rlp, rlp + lanes, ...; the window is walked by pointer steps of one row
+                const int WP = W >> 1, npair = min(kBlock, WP), lanes = kBlock / npair;
+                const int cp = tid % npair, rlp = tid / npair;
+                if (rlp < lanes)
+                    for (int c2 = cp; c2 < WP; c2 += npair)
+                        for (int p = rlp; p < rows + 2 * hn; p += lanes) {
+                            const int t = min(max(s - hn + p, 0), n - 1); // the row whose delta this entry holds
+                            const int q = t - (s - hp);                    // its entry in prev
+                            const cpx<T> *ph = reinterpret_cast<const cpx<T> *>(prev + q * W) + c2, *pl = ph;
+                            cpx<T> sum = {0, 0};
+                            T ft = 1;
+                            for (int tau = 1; tau <= a.delwin; ++tau) {
+                                ph += WP;
+                                pl -= WP;
+                                sum = cfma_r(*ph - *pl, ft, sum); // sum + tau (x[t + tau] - x[t - tau]) per column
+                                ft += (T)1;
+                            }
+                            const cpx<T> d = {quotient(sum.x), quotient(sum.y)};
+                            reinterpret_cast<cpx<T> *>(next + p * W)[c2] = d;
+                            const int row = s - hn + p;
+                            if (row >= s && row < s + rows)
+                                *reinterpret_cast<cpx<T> *>(base + (long long)row * a.step + o * W + 2 * c2) = d;
+                        }
+            } else if (rl < rowLanes) {
+                for (int c = col; c < W; c += ncol)
+                    for (int p = rl; p < rows + 2 * hn; p += rowLanes) {
+                        const int t = min(max(s - hn + p, 0), n - 1);
+                        const int q = t - (s - hp);
+                        const T *ph = prev + q * W + c, *pl = ph;
+                        T sum = 0, ft = 1;
+                        for (int tau = 1; tau <= a.delwin; ++tau) {
+                            ph += W;
+                            pl -= W;
+                            sum += ft * (*ph - *pl);
+                            ft += (T)1;
+                        }
+                        const T d = quotient(sum);
+                        next[p * W + c] = d;
+                        const int row = s - hn + p;
+                        if (row >= s && row < s + rows) base[(long long)row * a.step + o * W + c] = d;
+                    }
             }
             __syncthreads();
             T *tmp = prev;
