@@ -319,7 +319,7 @@ def main():
         prof = profile_numbers(args.workload, n_utts, args.precision)
         roofline = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                    "kernel": "static-feature kernel (k_lean256 / k_front)", "kernel_ms": kavg * 1e3,
+                    "kernel": "static-feature kernel (k_lean256: c2, c3; k_wide1024: c1, c4, c5; k_front in f64)", "kernel_ms": kavg * 1e3,
                     "algorithmic_bytes_per_frame": kernel_bytes,
                     "whole_pass": {"algorithmic_bytes_per_frame": pass_bytes,
                                    "frac": total_frames * pass_bytes * args.steps / elapsed / (HBM_PEAK * world)}}

@@ -43,6 +43,8 @@ lengths = [int(wlen + kw["inc"] * rng.integers(0, 60) + rng.integers(0, kw["inc"
 pcms = [tp._pcm(n, ch, bps, seed * 10 + i, sr, tone=0).tobytes() for i, n in enumerate(lengths)]
 print(kw, ch, bps)
 ocfg = oracle.make_config(**kw)
+if len(sys.argv) > 2:  # tuning overrides, e.g. noLean=1
+    ma.tuning(**{k: int(v) for k, v in (item.split("=") for item in sys.argv[2].split(","))})
 refs = [oracle.extract_pcm_bytes(ocfg, np.frombuffer(p, dtype=np.uint8), ch, bps) for p in pcms]
 gots = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), pcms, ch, bps, pad=int(rng.integers(0, 7)))
 kinds = np.array(column_kinds(kw) * kw["vecNum"])
