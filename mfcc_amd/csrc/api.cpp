@@ -245,6 +245,7 @@ struct Tuning {
     int tileFrames = 0, tileTables = 0, tileBlocks = 0; // general kernel tile: frames, tables in LDS, workgroups per CU
     int melPieces = 0;     // parts a mel segment is cut into (0: heuristic)
     int noMelMatrix = 0;   // no matrix-core mel filterbank
+    int leanWaves = 0;     // pipelined 256-point kernel: 8 = skip the 12-wave form
     int blocksPerCu = 0;   // resident workgroups per CU (0: heuristic)
     int noUttFinish = 0;   // deltas / z-norm by the row-block kernels even for short utterances
     int noFinishReg = 0;   // whole-utterance finishing kernel without its register variant
@@ -271,7 +272,7 @@ extern "C" int MFCCDebugTuning(const char *key, int value)
     const struct { const char *name; int Tuning::*field; } keys[] = {
         {"noLean", &Tuning::noLean}, {"pplog", &Tuning::pplog}, {"tileFrames", &Tuning::tileFrames},
         {"tileTables", &Tuning::tileTables}, {"tileBlocks", &Tuning::tileBlocks}, {"melPieces", &Tuning::melPieces},
-        {"noMelMatrix", &Tuning::noMelMatrix}, {"blocksPerCu", &Tuning::blocksPerCu}, {"noUttFinish", &Tuning::noUttFinish},
+        {"noMelMatrix", &Tuning::noMelMatrix}, {"leanWaves", &Tuning::leanWaves}, {"blocksPerCu", &Tuning::blocksPerCu}, {"noUttFinish", &Tuning::noUttFinish},
         {"noFinishReg", &Tuning::noFinishReg}, {"noFusedDelta", &Tuning::noFusedDelta}, {"leanChunk", &Tuning::leanChunk},
         {"debug", &Tuning::debug}};
     for (const auto &k : keys)
@@ -670,6 +671,7 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
         const int teamL = rowPitchL + 4 * zl;
         const int tabL = (((c->dctElems + 1) & ~1) + lean256_mel_steps(p->melSteps) * 64 + 2 * nz * 16 + nc + 3) & ~3;
         for (int pass = 0; pass < 2 && !p->lean256; ++pass) {
+            if (pass == 0 && tune.leanWaves == 8) continue;
             const int waves = lean256_waves(c->cfg.wlen, pass == 0);
             if (pass == 1 && waves == lean256_waves(c->cfg.wlen, true)) break;
             const size_t bytes = ((size_t)tabL + (size_t)waves * teamL) * sizeof(float);
