@@ -462,6 +462,46 @@ def test_batch_order_and_shift_invariance_at_full_size():
     assert np.array_equal(c[1:], a[0][:-1])
 
 
+def test_batch_order_and_shift_invariance_of_the_stereo_class_at_full_size():
+    """The same two properties at the size of the 2048-point stereo benchmark (44.1 kHz 24-bit stereo,
+    60 s files, left and right rows with cepstra, zero crossings, brightness and sub-bands): rows do
+    not depend on the file's place in the batch, and a delay of one hop shifts them by one frame."""
+    kw = dict(CONFIGS["c4"], preemphasise=0.0)
+    n, U, sr = 60 * 44100, 6, 44100
+    pcms = [_pcm(n, 2, 3, 700 + u, sr, tone=0) for u in range(U)]
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
+    a = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 2, 3)
+    perm = np.random.default_rng(2).permutation(U)
+    b = run_product_batch(ma, cfg, [pcms[i].tobytes() for i in perm], 2, 3)
+    for j, i in enumerate(perm):
+        assert np.array_equal(a[i], b[j], equal_nan=True)
+    assert a[0].shape == (ma.num_frames(n, kw["wlen"], kw["inc"]), 2 * len(column_kinds(kw)))
+    hop = kw["inc"] * 2 * 3
+    shifted = np.concatenate([np.zeros(hop, dtype=np.uint8), pcms[0]])[:n * 6]
+    c = run_product_batch(ma, cfg, [shifted.tobytes()], 2, 3)[0]
+    assert np.array_equal(c[1:], a[0][:-1], equal_nan=True)
+
+
+def test_shards_equal_the_whole_on_a_long_stereo_recording():
+    """Frame-sharded extraction of a ten-minute 44.1 kHz 24-bit stereo recording with the example
+    option set (306 columns, deltas over 9 frames): without z-norm 2, 3 and 7 frame ranges give the
+    bits of one; with z-norm (column sums added in shard order) they agree to 5e-5."""
+    n = 600 * 44100
+    pcm = _pcm(n, 2, 3, 801, 44100, tone=0)
+    kw = dict(CONFIGS["c5"], znormFlag=0)
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
+    one = ma.extract_recording(cfg, pcm, 2, 3, num_shards=1)
+    assert one.shape == (ma.num_frames(n, 1764, 882), 306)
+    for shards in (2, 3, 7):
+        many = ma.extract_recording(cfg, pcm, 2, 3, num_shards=shards, devices=[0] * shards)
+        assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
+    cfg = ma.make_config(precision=ma.PREC_F32, **CONFIGS["c5"])
+    one = ma.extract_recording(cfg, pcm, 2, 3, num_shards=1)
+    many = ma.extract_recording(cfg, pcm, 2, 3, num_shards=4, devices=[0] * 4)
+    assert np.array_equal(np.isnan(one), np.isnan(many))
+    assert float(np.nanmax(np.abs(one - many))) < 5e-5
+
+
 def test_linearity_of_the_power_path_at_full_size():
     """Scaling the PCM by 2 adds ln 4 to every log-mel value above the floor and to log-energy."""
     kw = dict(CONFIGS["c2"], energyFlag=1)
