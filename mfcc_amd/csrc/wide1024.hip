@@ -508,31 +508,36 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                 else if (F_S == 4) wide_bands<4>(pa, pb, l, e, ek);
                 else if (F_S == 2) wide_bands<2>(pa, pb, l, e, ek);
                 else wide_bands<16>(pa, pb, l, e, ek);
-                // the 64 lanes' partial sums through the (free) work area: [value i][lane], then lane
-                // (i, j) = (l % 16, l / 16) adds the 16 lanes 16 j .. 16 j + 15 of value i, and the four
-                // quarters are added by lane exchange: lane i < 16 ends with the total of e[i], lanes
-                // 16 + i with it too (ek likewise in a second pass)
-                T tot[2];
+                // the 64 lanes' partial sums through the (free) work area, [value i][lane]
+                // (both kinds at once: rows 0 .. 15 hold e, rows 16 .. 31 ek; lane (i, j) = (l % 32, l / 32)
+                // adds the lanes 32 j .. 32 j + 31 of row i, one lane exchange adds the two halves:
+                // lanes 0 .. 15 end with the totals of e, lanes 16 .. 31 with those of ek)
 #pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) Pw[g * 68 + l] = pass == 0 ? e[g] : ek[g]; // (rows of 64 + 4: the reads below then spread over the banks)
-                    group_sync<G>();
-                    const float4 *q4 = reinterpret_cast<const float4 *>(Pw + (l & 15) * 68 + (l >> 4) * 16);
-                    const float4 s0 = q4[0], s1 = q4[1], s2 = q4[2], s3 = q4[3];
-                    T sum = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
-                            (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-                    sum += __shfl_xor(sum, 16, 64);
-                    sum += __shfl_xor(sum, 32, 64);
-                    tot[pass] = sum;
-                    group_sync<G>();
+                for (int g = 0; g < 16; ++g) {
+                    Pw[g * 68 + l] = e[g]; // (rows of 64 + 4: the reads below then spread over the banks)
+                    Pw[(16 + g) * 68 + l] = ek[g];
                 }
-                // total power and its bin-weighted sum: over the bands, i.e. over lanes 0 .. S-1 of a row
-                const T eb = (l & 15) < F_S ? tot[0] : (T)0, ekb = (l & 15) < F_S ? tot[1] : (T)0;
-                const T total = group_sum<T, 16>(eb, nullptr, tt), num = group_sum<T, 16>(ekb, nullptr, tt);
+                group_sync<G>();
+                T tot = 0;
+                {
+                    const float4 *q4 = reinterpret_cast<const float4 *>(Pw + (l & 31) * 68 + (l >> 5) * 32);
+                    float4 sv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) sv[i] = q4[i];
+                    T part[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) part[i] = (sv[i].x + sv[i].y) + (sv[i].z + sv[i].w);
+                    tot = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+                    tot += __shfl_xor(tot, 32, 64);
+                }
+                group_sync<G>();
+                // total power (lanes 0 .. 15) and its bin-weighted sum (lanes 16 .. 31): over the bands,
+                // i.e. over lanes 0 .. S-1 of a row of 16
+                const T totals = group_sum<T, 16>((l & 15) < F_S ? tot : (T)0, nullptr, tt);
+                const T num = __shfl(totals, 16, 64);
                 const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
-                if (l < F_S) fo[subAt + l] = tot[0] / total;
-                if (l == 0 && a.brightFlag) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / total / (T)NC;
+                if (l < F_S) fo[subAt + l] = tot / totals;
+                if (l == 0 && a.brightFlag) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / totals / (T)NC;
             } else if (F_S > 0) {
 #pragma unroll
                 for (int q = 0; q < NPAIR; ++q) {
