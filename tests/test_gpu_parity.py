@@ -502,6 +502,68 @@ def test_shards_equal_the_whole_on_a_long_stereo_recording():
     assert float(np.nanmax(np.abs(one - many))) < 5e-5
 
 
+def test_byte_offsets_beyond_two_gib():
+    """A PCM buffer larger than 2^31 bytes (2.4 hours of 44.1 kHz 24-bit stereo, the example option
+    set): (1) an utterance that starts beyond that offset comes out bit for bit as it does alone;
+    (2) the frames of the whole recording that lie beyond it equal those of an excerpt (static
+    columns: every frame; delta columns: the frames whose regression window lies inside the excerpt)."""
+    import ctypes as C
+    import threading
+    import torch
+    kw = CONFIGS["c1a"]
+    sr, inc, wlen, bpi = 44100, kw["inc"], kw["wlen"], 6
+    n = 400_000_000
+    assert n * bpi > 2 ** 31 + 2 ** 27
+    buf = np.empty(n * bpi, dtype=np.uint8)
+    L, threads = ma.lib(), 16
+    per = (n + threads - 1) // threads
+
+    def fill(t):
+        a, b = t * per, min(n, (t + 1) * per)
+        for ch in range(2):
+            L.MFCCSynthPcmAt(C.c_void_p(buf.ctypes.data + a * bpi), 2, ch, 3, a, b - a, C.c_uint64(0x5EED0777 + ch), sr, 0)
+
+    ths = [threading.Thread(target=fill, args=(t,)) for t in range(threads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    T = ma.num_frames(n, wlen, inc)
+    f0 = T - 2000                      # first frame of the excerpt
+    s0 = f0 * inc                      # its first sample: byte offset 6 s0 > 2^31
+    assert s0 * bpi > 2 ** 31
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
+    ctx = ma.Context(cfg, 0)
+    dev = torch.from_numpy(buf).cuda()
+    alone = ma.Plan(ctx, 2, 3, [0], [n - s0]).extract(dev[s0 * bpi:].clone()).cpu().numpy()
+    assert alone.shape == (2000, 306)
+    two = ma.Plan(ctx, 2, 3, [0, s0 * bpi], [s0, n - s0])
+    out = two.extract(dev).cpu().numpy()
+    assert np.array_equal(out[two.row_offset(1):], alone, equal_nan=True)
+    del out
+    whole = ma.Plan(ctx, 2, 3, [0], [n]).extract(dev).cpu().numpy()
+    assert whole.shape == (T, 306)
+    assert np.array_equal(whole[f0:, :102], alone[:, :102], equal_nan=True)
+    halo = 2 * kw["delwin"]
+    assert np.array_equal(whole[f0 + halo:T - halo, 102:], alone[halo:2000 - halo, 102:], equal_nan=True)
+    ctx.close()
+
+
+def test_ragged_batch_rows_equal_the_lone_utterances_at_size():
+    """600 utterances of 2 to 20 s (13 MFCC + C0 + energy, deltas, z-norm: the row-block delta and
+    z-norm kernels over 600 000 rows): a sample of them, the shortest and the longest included,
+    comes out bit for bit as it does alone."""
+    kw = CONFIGS["c3"]
+    rng = np.random.default_rng(12)
+    lengths = rng.integers(2 * 16000, 20 * 16000 + 1, size=600)
+    pcms = [_pcm(int(n), 1, 2, 3000 + u, 16000, tone=0) for u, n in enumerate(lengths)]
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
+    got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 1, 2)
+    assert sum(g.shape[0] for g in got) == sum(ma.num_frames(int(n), 400, 160) for n in lengths)
+    picks = {int(np.argmin(lengths)), int(np.argmax(lengths)), 0, 299, 599} | set(int(i) for i in rng.integers(0, 600, size=7))
+    for u in sorted(picks):
+        alone = run_product_batch(ma, cfg, [pcms[u].tobytes()], 1, 2)[0]
+        assert np.array_equal(got[u], alone, equal_nan=True), u
+
+
 def test_linearity_of_the_power_path_at_full_size():
     """Scaling the PCM by 2 adds ln 4 to every log-mel value above the floor and to log-energy."""
     kw = dict(CONFIGS["c2"], energyFlag=1)
