@@ -13,8 +13,9 @@
 //     10.4 KB instead of 14 - 28 KB, which is what lets 8 waves share a CU.  Every (frame, row)
 //     round expands the three instants a lane needs per point pair straight from those bytes;
 //   - the next frame's bytes are requested (16-byte vectors into registers) once the FFT of the
-//     frame's last row has freed its registers and stored over the current ones at the end of
-//     that round; frames at the first or last bytes of the buffer are patched byte by byte;
+//     frame's last row has freed its registers and stored over the current ones before that
+//     round's results go out; frames at the first or last bytes of the buffer are patched byte by
+//     byte;
 //   - waves draw chunks of consecutive frames from a shared counter (see lean256.hip).
 #include <hip/hip_runtime.h>
 
