@@ -137,6 +137,31 @@ def test_lean_kernel_modes(oracle, wlen, bank, cepstral):
     _compare(got, ref, kw, False)
 
 
+@pytest.mark.parametrize("wlen,bank,vec", [(1025, 8, 1), (1100, 64, 2), (1153, 23, 3), (1500, 40, 4), (1665, 3, 2),
+                                           (1764, 26, 4), (1792, 40, 1), (1793, 57, 2), (2000, 12, 3), (2047, 40, 2),
+                                           (2048, 64, 4)])
+@pytest.mark.parametrize("cepstral", [False, True])
+@pytest.mark.parametrize("extras", [False, True])
+def test_stereo_2048_point_kernel_modes(oracle, wlen, bank, vec, cepstral, extras):
+    """24-bit stereo frames of 1025 to 2048 samples take the one-wave-per-frame kernel: every
+    count of first-stage inputs per lane (9 to 16), 1 to 4 derived rows, few and many channels (mel
+    segments cut into 1 to 10 parts of 15 or more bins), log-mel and cepstral outputs, with and
+    without zero crossings / brightness / sub-bands / energy, odd frame shifts, a ragged last
+    frame and utterances that start at odd byte offsets."""
+    inc = wlen // 3 + 1
+    kw = dict(sampleRate=44100, lowpassfre=-1 if bank % 2 else 30, hipassfre=-1 if bank % 3 else 20000,
+              preemphasise=0.97, wlen=wlen, inc=inc, vecNum=vec, fbankFlag=0 if cepstral else 1, bankNum=bank,
+              MFCCNum=min(bank, 20), MFCC0thFlag=1 if cepstral else 0, energyFlag=1 if extras else 0,
+              zeroCrossingFlag=1 if extras else 0, brightFlag=1 if extras else 0,
+              subBandEFlag=(8 if bank % 2 else 5) if extras else 0)
+    pcms = [_pcm(wlen + k * inc + 7, 2, 3, wlen + bank + k, 44100, tone=0) for k in (9, 1, 0)]
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
+    got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 2, 3, pad=3)
+    for g, p in zip(got, pcms):
+        ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), p, 2, 3)
+        _compare(g, ref, kw, False)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MFCC_FUZZ_SEEDS", "48"))))
 def test_random_configurations(oracle, seed, tuning):
     """Seeded random walk over the option space (frame geometry, channel layouts, feature flags,
