@@ -97,6 +97,7 @@ struct MFCCPlan {
     int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
     bool lean256 = false; // mode 2 run by the pipelined 256-point kernel
     bool wide1024 = false; // 24-bit stereo, 1024 complex points: run by k_wide1024 (raw PCM bytes in LDS)
+    int pipe64 = 0;        // double precision, run by k_pipe64: 8 (mono 16-bit, 256 complex points) or 10 (24-bit stereo, 1024)
     int leanWaves = 0;    // ... with this many waves per workgroup
     int leanChunk = 0;    // ... tiles per chunk override (0: heuristic, -1: fixed ranges)
     std::vector<float> melW;
@@ -287,6 +288,60 @@ extern "C" int MFCCDebugTuning(const char *key, int value)
 // plans
 // ------------------------------------------------------------------------------------------
 
+// k_pipe64's mel sums: every segment (the bins whose lower channel is s, s = 0 .. P) is cut into
+// at most 10 parts of at most partBins bins; part i goes to lane i % G of a frame in round i / G
+// (G = 16 lanes and at most 64 parts, or 64 lanes and at most 128 parts).  partBins is the value
+// with the fewest bin steps per frame (rounds x partBins).  Table: 128 x {first bin, end bin, part or
+// -1, 0}, then per channel {first part, parts} of the segment whose upper shares it takes (segment
+// ch) and of the one whose lower shares it takes (segment ch + 1).  false: the filterbank has more
+// segments than the table has parts.
+static bool pipe64_part_table(MFCCPlan *p, int cls, bool debug)
+{
+    const MFCCContext *c = p->ctx;
+    const int S1 = c->cfg.bankNum + 1, nc = c->tab.nc, G = pipe64_lanes(cls), maxParts = G == 16 ? 64 : 128;
+    std::vector<int> segB(S1, 0), segE(S1, 0), partBegin(S1 + 2, 0);
+    for (int k = 0; k < nc; ++k) {
+        const int ch = c->tab.loChan[k];
+        if (ch < 0 || ch >= S1) continue;
+        if (segE[ch] == 0) segB[ch] = k;
+        segE[ch] = k + 1;
+    }
+    int longest = 0;
+    for (int sIdx = 0; sIdx < S1; ++sIdx) longest = std::max(longest, segE[sIdx] - segB[sIdx]);
+    int partBins = 0, bestCost = 0;
+    for (int cand = 1; cand <= std::max(nc, 1); ++cand) {
+        int total = 0;
+        for (int sIdx = 0; sIdx < S1; ++sIdx) total += std::max(1, (segE[sIdx] - segB[sIdx] + cand - 1) / cand);
+        if ((longest + cand - 1) / cand <= 10 && total <= maxParts) {
+            const int cost = ((total + G - 1) / G) * ((cand + 3) / 4 * 4 + 2); // bin steps (in fours) + the round's fixed price
+            if (!partBins || cost < bestCost) partBins = cand, bestCost = cost;
+        }
+        if (cand >= longest) break;
+    }
+    if (!partBins) return false;
+    p->laneSeg.assign((size_t)(128 + 64) * 4, 0);
+    for (int i = 0; i < 128; ++i) p->laneSeg[4 * i + 2] = -1;
+    int parts = 0;
+    for (int sIdx = 0; sIdx < S1; ++sIdx) {
+        const int len = segE[sIdx] - segB[sIdx], n = std::max(1, (len + partBins - 1) / partBins);
+        partBegin[sIdx] = parts;
+        for (int j = 0; j < n; ++j, ++parts) {
+            p->laneSeg[4 * parts + 0] = segB[sIdx] + (int)((long)len * j / n);
+            p->laneSeg[4 * parts + 1] = segB[sIdx] + (int)((long)len * (j + 1) / n);
+            p->laneSeg[4 * parts + 2] = parts;
+        }
+    }
+    partBegin[S1] = partBegin[S1 + 1] = parts;
+    for (int ch = 0; ch < c->cfg.bankNum; ++ch) {
+        int32_t *e = &p->laneSeg[(size_t)(128 + ch) * 4];
+        e[0] = partBegin[ch], e[1] = partBegin[ch + 1] - partBegin[ch];
+        e[2] = partBegin[ch + 1], e[3] = partBegin[ch + 2] - partBegin[ch + 1];
+    }
+    p->maxSeg = (parts + G - 1) / G;
+    if (debug) fprintf(stderr, "mfcc plan: %d mel parts of at most %d bins\n", parts, partBins);
+    return true;
+}
+
 // LDS geometry of the static-feature kernel for this plan: frames per tile, whether the window /
 // twiddle / split tables get an LDS copy, and how many workgroups fit a CU.
 static int choose_tile(MFCCPlan *p, bool allowWide = true)
@@ -309,11 +364,17 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
     const bool wideCand = plainFbank && allowWide && prec == MFCC_PREC_F32 && !c->cfg.zeroMeanSigFlag && !c->cfg.fftLength &&
                           p->totalRows < 0x7fffffffLL && !tune.noLean &&
                           wide1024_applies(log2nc, p->channels, p->bps, c->cfg.wlen) && c->cfg.bankNum <= 64;
-    int pplog = (front_variant_exists(log2nc, 3) && !leanCand && !wideCand) ? 3 : 4;
+    // double precision, one of the two benchmark input classes: k_pipe64 (raw PCM bytes in LDS, wave-sized teams)
+    const int pipeCls = (plainFbank && allowWide && prec == MFCC_PREC_F64 && !c->cfg.zeroMeanSigFlag && !c->cfg.fftLength &&
+                         p->totalRows < 0x7fffffffLL && !tune.noLean && c->cfg.bankNum <= 64 &&
+                         2 * std::max(c->cfg.subBandEFlag, 1) <= nc / 16)
+                            ? pipe64_class(log2nc, p->channels, p->bps, c->cfg.wlen, c->cfg.inc)
+                            : 0;
+    int pplog = (front_variant_exists(log2nc, 3) && !leanCand && !wideCand && !pipeCls) ? 3 : 4;
     // (double precision, 256 complex points: 16 points per lane with 8-frame tiles measured 6 % ahead
     // of 8 points with 2-frame tiles, 17.9 vs 19.0 ms on 10,000 ten-second utterances)
     if (prec == MFCC_PREC_F64 && log2nc == 8) pplog = 4;
-    if (tune.pplog > 0 && front_variant_exists(log2nc, tune.pplog) && !wideCand) pplog = tune.pplog;
+    if (tune.pplog > 0 && front_variant_exists(log2nc, tune.pplog) && !wideCand && !pipeCls) pplog = tune.pplog;
     p->pplog = pplog;
     const int teams = front_teams(log2nc, pplog);
     const int groups = front_groups(log2nc, pplog) / teams; // frames in flight per team
@@ -623,6 +684,34 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
     p->mode = (leanCand && (pplog == 3 || pplog == 4) && bestTab) ? (p->melSteps > 0 ? 2 : 1) : 0;
     p->leanChunk = tune.leanChunk;
     p->wide1024 = false;
+    p->pipe64 = 0;
+    if (pipeCls) {
+        // a wave's LDS region: the tile's raw bytes, then one work area per frame in flight; in front
+        // of the regions the filterbank weights and (256-point class) window, twiddles, split factors
+        // and cepstral table
+        const int rawEl = pipe64_raw_bytes(pipeCls, c->cfg.wlen, c->cfg.inc) / 8;
+        const int gt = pipe64_frames_per_tile(pipeCls);
+        const int teamL = rawEl + gt * pipe64_area_elems(pipeCls);
+        const int tabL = pipe64_tab_elems(pipeCls, c->cfg.wlen, c->dctElems);
+        const size_t bytes = ((size_t)tabL + (size_t)pipe64_waves() * teamL) * sizeof(double);
+        if (bytes > kLds || !pipe64_part_table(p, pipeCls, tune.debug != 0)) return choose_tile(p, false);
+        p->pipe64 = pipeCls;
+        p->framesPerTile = gt;
+        p->rowPitch = rawEl;
+        p->rawOrZElems = gt * pipe64_area_elems(pipeCls);
+        p->fbkElems = 0;
+        p->featElems = 0;
+        p->teamElems = teamL;
+        p->tabElems = tabL;
+        p->activeTeams = pipe64_waves();
+        p->ldsBytes = bytes;
+        p->blocksPerCu = 1;
+        p->mode = 0;
+        if (tune.debug)
+            fprintf(stderr, "mfcc plan: double-precision pipelined kernel, %d complex points, %d waves per workgroup, LDS %zu B\n", 1 << pipeCls,
+                    pipe64_waves(), bytes);
+        return MFCC_OK;
+    }
     if (wideCand) {
         // a wave's LDS region: the frame's raw bytes, one work area, the frame's log-mel rows
         const int rawEl = wide1024_raw_bytes(c->cfg.wlen) / 4;
@@ -759,8 +848,8 @@ static int finish_plan(MFCCPlan *p)
             const uint64_t off = (uint64_t)(d.byteOff + first0 * bpi);
             if (off > kTileOffMask) return set_error("PCM buffer larger than 2^48 bytes"), MFCC_E_ARG;
             TileDesc td;
-            if (p->lean256 || p->wide1024) {
-                // k_lean256's / k_wide1024's form: offset of the first sample itself; bit 60: it starts the signal;
+            if (p->lean256 || p->wide1024 || p->pipe64) {
+                // k_lean256's / k_wide1024's / k_pipe64's form: offset of the first sample itself; bit 60: it starts the signal;
                 // bit 61: a 16-byte vector of the fetch (which begins one sample earlier) would
                 // leave the planned bytes
                 const int64_t src = d.byteOff + first * bpi;
@@ -865,7 +954,7 @@ static int finish_plan(MFCCPlan *p)
     }
     HIP_TRY(hipMalloc((void **)&p->dLaneSeg, std::max<size_t>(p->laneSeg.size(), 4) * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p->dLaneSeg, p->laneSeg.data(), p->laneSeg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    if (p->lean256 || p->wide1024) {
+    if (p->lean256 || p->wide1024 || p->pipe64) {
         HIP_TRY(hipMalloc((void **)&p->dWork, 2 * sizeof(unsigned)));
         HIP_TRY(hipMemset(p->dWork, 0, 2 * sizeof(unsigned)));
     }
@@ -1248,6 +1337,23 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
             a.work = p->dWork;
             const int rcl = launch_lean256(a, nb, p->ldsBytes, p->leanWaves, stream);
             if (rcl) return set_error("static-feature kernel launch failed (HIP error %d)", rcl), MFCC_E_DEVICE;
+            return MFCC_OK;
+        }
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (p->pipe64) {
+            const int waves = p->activeTeams;
+            const int64_t teamsMax = (int64_t)p->numCus * waves;
+            int chunk = p->numTiles <= teamsMax ? 1 : (int)std::max<int64_t>(2, std::min<int64_t>(32, p->numTiles / (8 * teamsMax)));
+            if (p->leanChunk > 0) chunk = p->leanChunk;
+            const int64_t chunks = (p->numTiles + chunk - 1) / chunk;
+            const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((chunks + waves - 1) / waves, p->numCus));
+            a.numUtts = p->numUtts;
+            a.planEnd = p->planEnd;
+            a.tilesPerTeam = chunk;
+            a.work = p->dWork;
+            const int rcp = launch_pipe64(a, p->pipe64, nb, p->ldsBytes, stream);
+            if (rcp) return set_error("static-feature kernel launch failed (HIP error %d)", rcp), MFCC_E_DEVICE;
             return MFCC_OK;
         }
     }

@@ -162,6 +162,15 @@ bool wide1024_applies(int log2nc, int channels, int bps, int wlen);
 int wide1024_waves();
 int wide1024_raw_bytes(int wlen);         // LDS bytes a wave reserves for a frame's raw PCM
 int launch_wide1024(const FrontArgs<float> &a, int numBlocks, size_t ldsBytes, void *stream);
+// pipe64.hip: double precision, mono 16-bit with 256 complex points or 24-bit stereo with 1024
+int pipe64_class(int log2nc, int channels, int bps, int wlen, int inc); // 0: not taken, else 8 or 10
+int pipe64_waves();
+int pipe64_frames_per_tile(int cls);
+int pipe64_lanes(int cls);                // lanes that share one frame
+int pipe64_raw_bytes(int cls, int wlen, int inc); // LDS bytes a wave reserves for a tile's raw PCM
+int pipe64_area_elems(int cls);           // doubles per frame work area
+int pipe64_tab_elems(int cls, int wlen, int dctElems); // doubles of the shared tables in LDS
+int launch_pipe64(const FrontArgs<double> &a, int cls, int numBlocks, size_t ldsBytes, void *stream);
 bool front_variant_exists(int log2nc, int pplog); // pplog: log2 of complex points per lane (4, 3, 2)
 int front_groups(int log2nc, int pplog);          // frames in flight per workgroup
 int front_teams(int log2nc, int pplog);           // independent teams (tile streams) per workgroup

@@ -1,0 +1,710 @@
+// Double-precision static-feature kernel for the two input classes the benchmarks name: mono 16-bit
+// PCM with frames of at most 512 samples (256 complex points, 16 lanes x 16 points per frame, four
+// frames per wave) and 24-bit stereo PCM with frames of 1025 .. 2048 samples (1024 complex points,
+// 64 lanes x 16 points, one frame per wave).  The reference computes in double throughout
+// (rows main.c:198-207, PreEmphasise main.c:208, zeroCrossingRate main.c:227, Ham main.c:229,
+// Wave2FBank mfcc.c:125-177, brightness / sub-bands main.c:235-236, FBank2MFCC / FBank2C0
+// mfcc.c:180-208, row layout main.c:241-249); this kernel is its arithmetic at that precision,
+// organised as the single-precision kernels of lean256.hip / wide1024.hip are:
+//   - a wave is a team of its own (wave-level synchronisation only), eight waves per workgroup, one
+//     workgroup per CU; waves draw chunks of consecutive tiles from a shared counter;
+//   - a tile is one round of frames (4 or 1).  What a wave keeps of it in LDS is the RAW interleaved
+//     PCM bytes; every (frame, row) round expands the instants a lane needs straight from them, in
+//     double with separately rounded product and difference, so every sample (and its sign, for
+//     the zero crossings) is the reference's bit for bit;
+//   - a work area holds one double per complex point: the transposing exchanges between the FFT
+//     stages move real and imaginary parts one after the other (same LDS bandwidth, half the
+//     footprint), the last stage stays in registers, and only the upper half of the spectrum
+//     goes through the area again for the real-FFT split;
+//   - the next tile's bytes are requested into registers during the round and stored over the
+//     current ones at its end.
+#include <hip/hip_runtime.h>
+
+#include "front_util.h"
+#include "stamps.h"
+#include <algorithm>
+#include <atomic>
+#include <type_traits>
+
+namespace mfcc {
+
+namespace {
+
+constexpr int kPipeWaves = 8;
+constexpr int kPipeParts = 128; // entries of the mel part table (the channel table follows it)
+
+typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
+typedef unsigned int u2u __attribute__((ext_vector_type(2), aligned(1)));
+typedef unsigned int u4s __attribute__((ext_vector_type(4)));
+
+// One tile as the pipeline sees it (all wave-uniform): the first three dwords of its TileDesc in
+// the encoding the pipelined kernels share (byte offset of the tile's first sample, bits 48..59
+// frames, bit 60: the tile starts the signal, bit 61: a vector of its fetch would leave the planned bytes).
+struct PipeTile {
+    unsigned w0, w1;
+    int outRow;
+    __device__ __forceinline__ int nf() const { return (int)((w1 >> 16) & 0xfffu); }
+    __device__ __forceinline__ bool valid() const { return nf() != 0; }
+    __device__ __forceinline__ bool first() const { return (w1 >> 28) & 1u; }
+    __device__ __forceinline__ bool edge() const { return (w1 >> 29) & 1u; }
+    __device__ __forceinline__ long long src() const { return (long long)(((unsigned long long)(w1 & 0xffffu) << 32) | w0); }
+};
+
+__device__ __forceinline__ int sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ PipeTile pipe_desc(const TileDesc *tab, int idx, bool valid)
+{
+    PipeTile t = {0u, 0u, 0};
+    if (valid) {
+        typedef const __attribute__((address_space(4))) u4s *cptr;
+        const u4s d = reinterpret_cast<cptr>(reinterpret_cast<unsigned long long>(tab))[idx];
+        t.w0 = d.x;
+        t.w1 = d.y;
+        t.outRow = (int)d.z;
+    }
+    return t;
+}
+
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// sum over the G lanes of a frame (G = 16: one row of lanes, G = 64: the wave)
+template <int G>
+__device__ __forceinline__ double frame_sum(double v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ int frame_sum(int v) { return group_sum<int, G>(v, nullptr, 0); }
+
+} // namespace
+
+// LOG2NC: 8 (CH 1, BPS 2) or 10 (CH 2, BPS 3).  NZ: first-stage inputs of a lane that can be
+// non-zero, ceil(wlen / (2 G)).
+template <int LOG2NC, int CH, int BPS, int NZ>
+__global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<double> a)
+{
+    constexpr int NC = 1 << LOG2NC, G = NC / 16, GT = 64 / G, PPL = 16, NPAIR = 8, WAVES = kPipeWaves;
+    constexpr int BPI = CH * BPS;
+    constexpr int PFN = G == 16 ? 2 : 11;  // 16-byte vectors of a tile's fetch per lane
+    constexpr int NPL = G == 16 ? 4 : 2;   // mel parts per lane
+    constexpr int CHL = 64 / G;            // filterbank channels per lane
+    constexpr bool TABLDS = G == 16;       // window, twiddles, split factors and cepstral table in LDS
+    constexpr bool EARLY = PFN <= 2;       // the next tile's bytes are requested at the start of the round
+    constexpr int ZP = NC + NC / 16;       // doubles per work area
+    constexpr int DW = G == 16 ? 2 : 6;    // dwords a lane reads per sample pair: instants 2n-1 .. 2n+2
+    typedef double T;
+    STAMP_DECL
+    STAMP_START;
+    const int tid = threadIdx.x;
+    const int wave = sgpr(tid >> 6);
+    const int tt = tid & 63;
+    const int l = tt & (G - 1), grp = tt / G;
+
+    // LDS: [filterbank weights (NC + 8) | TABLDS: window pairs (NZ G) | twiddles (15 x 16) | split
+    // factors (NC / 2) | cepstral table] then one region per wave: [raw PCM bytes | GT work areas]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *lwL = reinterpret_cast<T *>(smem);
+    cpx<T> *winL = reinterpret_cast<cpx<T> *>(lwL + NC + 8);
+    cpx<T> *twL = winL + NZ * G;
+    cpx<T> *swL = twL + 15 * 16;
+    T *dctL = reinterpret_cast<T *>(swL + NC / 2);
+    unsigned char *region = smem + ((size_t)a.tabElems + (size_t)wave * a.teamElems) * sizeof(T);
+    unsigned *raw = reinterpret_cast<unsigned *>(region);
+    T *Zt = reinterpret_cast<T *>(region) + a.rowPitch + grp * ZP; // (rowPitch: elements reserved for the raw bytes)
+    cpx<T> *Zc = reinterpret_cast<cpx<T> *>(Zt);
+
+    for (int i = tid; i < NC + 8; i += WAVES * 64) lwL[i] = i < NC ? a.loWt[i] : (T)0;
+    if constexpr (TABLDS) {
+        for (int i = tid; i < NZ * G; i += WAVES * 64) winL[i] = reinterpret_cast<const cpx<T> *>(a.window)[i];
+        for (int i = tid; i < 15 * 16; i += WAVES * 64) twL[i] = reinterpret_cast<const cpx<T> *>(a.tw)[i];
+        for (int i = tid; i < NC / 2; i += WAVES * 64) swL[i] = reinterpret_cast<const cpx<T> *>(a.splitTw)[i];
+        for (int i = tid; i < a.dctElems; i += WAVES * 64) dctL[i] = a.dctT[i];
+    }
+    // every value a masked sum may read from a work area is a finite number from here on
+    for (int i = l; i < ZP; i += G) Zt[i] = (T)0;
+    __syncthreads();
+    const cpx<T> *winT = TABLDS ? winL : reinterpret_cast<const cpx<T> *>(a.window);
+    const cpx<T> *twT = TABLDS ? twL : reinterpret_cast<const cpx<T> *>(a.tw);
+    const cpx<T> *swT = TABLDS ? swL : reinterpret_cast<const cpx<T> *>(a.splitTw);
+    const T *dctT = TABLDS ? dctL : a.dctT;
+
+    // mel segment parts of the lane and the part ranges of its channels (see pipe64 tables, api.cpp)
+    const int4 *lseg = reinterpret_cast<const int4 *>(a.laneSeg);
+    int partB[NPL], partE[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+        const int4 e = lseg[l + G * j];
+        partB[j] = e.x;
+        partE[j] = e.z >= 0 ? e.y : e.x;
+    }
+    int4 chanParts[CHL];
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) {
+        const int ch = l + G * j;
+        chanParts[j] = ch < a.P ? lseg[kPipeParts + ch] : make_int4(0, 0, 0, 0);
+    }
+    const T preK = a.preK;
+    const int JW = a.M + a.c0Flag;
+    const int F_V = CH == 1 ? 1 : a.V, F_S = a.S;
+    const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
+
+    // The wave's stream of tiles: chunks of a.tilesPerTeam consecutive tiles, the first one by the
+    // wave's index, every further one drawn from a counter the waves of the launch share.  a.work[0]
+    // is that counter, zero at launch; the last wave to finish (a.work[1] counts them) zeroes it again.
+    const int teamId = blockIdx.x * WAVES + wave, numTeams = gridDim.x * WAVES, C = a.tilesPerTeam;
+    int chunkBase = teamId * C, chunkPos = 0, nextBase = 0;
+    bool haveNext = false, needDraw = true;
+    auto draw = [&]() {
+        unsigned drawn = 0;
+        if (tt == 0) drawn = atomicAdd(a.work, 1u);
+        nextBase = (sgpr((int)drawn) + numTeams) * C;
+        haveNext = true;
+        needDraw = false;
+    };
+    auto next_tile = [&]() {
+        if (chunkPos == C) {
+            if (!haveNext) {
+                if (!needDraw) return -1;
+                draw();
+            }
+            chunkBase = nextBase;
+            chunkPos = 0;
+            haveNext = false;
+            needDraw = chunkBase < a.numTiles;
+        }
+        const int id = chunkBase + chunkPos;
+        if (id >= a.numTiles) return -1;
+        ++chunkPos;
+        return id;
+    };
+    auto draw_step = [&]() {
+        if (needDraw && !haveNext) draw();
+    };
+    auto next_tile_s = [&]() {
+        const int id = sgpr(next_tile());
+        chunkBase = sgpr(chunkBase);
+        chunkPos = sgpr(chunkPos);
+        nextBase = sgpr(nextBase);
+        return id;
+    };
+    auto finish = [&]() {
+        __threadfence();
+        if (tt == 0 && atomicInc(a.work + 1, (unsigned)numTeams - 1u) == (unsigned)numTeams - 1u) {
+            __hip_atomic_store(a.work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (chunkBase >= a.numTiles) {
+        finish();
+        STAMP_FLUSH;
+        return;
+    }
+    const TileDesc *tab = a.tiles;
+    int id = next_tile_s();
+    PipeTile cur = pipe_desc(tab, id, true);
+    id = next_tile_s();
+    PipeTile nx = pipe_desc(tab, id < 0 ? 0 : id, id >= 0);
+    id = next_tile_s();
+    PipeTile nn = pipe_desc(tab, id < 0 ? 0 : id, id >= 0);
+
+    // Bytes of a tile: its frames' instants and the predecessor of the first.  Vector j of lane tt =
+    // bytes 16 (tt + 64 j) .. + 15, byte 0 being the first byte of that predecessor.  Tiles at the
+    // first or last bytes of the buffer keep every vector inside it by clamping its offset
+    // (store_raw then redoes such a tile byte by byte).
+    auto tile_bytes = [&](const PipeTile &t) { return ((t.nf() - 1) * a.inc + a.wlen + 1) * BPI; };
+    auto fetch = [&](const PipeTile &t, u4u (&pf)[PFN]) {
+        const long long off0 = t.src() - BPI;
+        int lo = 0, hi = 16 * (((tile_bytes(t) + 15) >> 4) - 1);
+        if (t.edge()) {
+            lo = (int)(off0 < 0 ? -off0 : 0);
+            hi = (int)min(a.planEnd - 16 - off0, (long long)hi);
+        }
+        const unsigned char *g = a.pcm + off0;
+#pragma unroll
+        for (int j = 0; j < PFN; ++j) pf[j] = *reinterpret_cast<const u4u *>(g + min(max(16 * (tt + j * 64), lo), hi));
+    };
+    auto store_raw = [&](const PipeTile &t, const u4u (&pf)[PFN]) {
+        const int nbytes = tile_bytes(t), nvec = (nbytes + 15) >> 4;
+#pragma unroll
+        for (int j = 0; j < PFN; ++j) {
+            const int vj = tt + j * 64;
+            if (vj < nvec) reinterpret_cast<uint4 *>(raw)[vj] = make_uint4(pf[j].x, pf[j].y, pf[j].z, pf[j].w);
+        }
+        if (t.edge()) {
+            const long long off0 = t.src() - BPI;
+            unsigned char *rb = reinterpret_cast<unsigned char *>(raw);
+            for (int b = tt; b < nbytes; b += 64) {
+                const long long g = off0 + b;
+                rb[b] = (g >= 0 && g < a.planEnd) ? a.pcm[g] : (unsigned char)0;
+            }
+        }
+    };
+    // One byte read per 128-byte line of a tile's bytes, so that its fetch finds them in L2.
+    unsigned warm0 = 0, warm1 = 0;
+    auto warm = [&](const PipeTile &t) {
+        const long long off0 = max(t.src() - BPI, 0ll), last = a.planEnd - 1;
+        const int nb = tile_bytes(t);
+        if (tt * 128 < nb) warm0 = a.pcm[min(off0 + tt * 128, last)];
+        if ((tt + 64) * 128 < nb) warm1 = a.pcm[min(off0 + (tt + 64) * 128, last)];
+    };
+
+    {
+        u4u pf0[PFN];
+        fetch(cur, pf0);
+        store_raw(cur, pf0);
+        wave_fence();
+    }
+
+    T lvr[4] = {0, 0, 0, 0}; // log-mel values of the lane's channels: [channel slot] (G = 16) or [row] (G = 64)
+
+    // One (frame, row) round.  LAST: the tile's last row.
+    auto round = [&](const int vv, auto lastTag) {
+        constexpr bool LAST = decltype(lastTag)::value;
+        u4u pf[LAST ? PFN : 1];
+        const int nf = cur.nf();
+        const int fr = grp < nf ? grp : 0; // frame slots past the tile's last frame redo frame 0
+        const bool firstTile = cur.first();
+        T *fo = a.out + ((long long)cur.outRow + fr) * a.step + vv * a.D;
+        const bool live = grp < nf;
+        // (tables read through L1: the lane index is made opaque once per round, so that what derives
+        // from it is recomputed here instead of being hoisted out of the tile loop and spilled)
+        int lq = l;
+        if constexpr (!TABLDS) asm volatile("" : "+v"(lq));
+        STAMP(0);
+        if constexpr (LAST && EARLY) {
+            if (nx.valid()) {
+                draw_step();
+                fetch(nx, pf);
+            }
+        }
+        if constexpr (!EARLY) {
+            if (vv == 0 && nx.valid()) warm(nx);
+        }
+
+        // ---- the lane's sample pairs (2n, 2n+1), n = l + G r, of derived row vv from the raw bytes
+        //      (rows main.c:198-207), pre-emphasised over the whole signal (PreEmphasise main.c:208,
+        //      first-sample rule for the signal's first sample), zero crossings of the un-windowed
+        //      samples (main.c:227), Hamming window (main.c:229), frame energy (mfcc.c:138-142)
+        cpx<T> v[PPL];
+        int zcn = 0;
+        {
+            // instants 2n-1 (predecessor), 2n, 2n+1, 2n+2 start at byte (frame start + 2n) BPI
+            const unsigned *src = raw + (CH == 1 ? ((fr * a.inc) >> 1) + l : 3 * l);
+#pragma unroll
+            for (int r = 0; r < NZ; ++r) {
+                unsigned d[DW];
+                if constexpr (G == 16) {
+                    d[0] = src[G * r];
+                    d[1] = src[G * r + 1];
+                } else {
+                    const u4u q = *reinterpret_cast<const u4u *>(src + 3 * G * r);
+                    const u2u q2 = *reinterpret_cast<const u2u *>(src + 3 * G * r + 4);
+                    d[0] = q.x, d[1] = q.y, d[2] = q.z, d[3] = q.w, d[4] = q2.x, d[5] = q2.y;
+                }
+                T x[4];
+                if constexpr (CH == 1) {
+                    x[0] = (T)(int)(short)(d[0] & 0xffffu);
+                    x[1] = (T)((int)d[0] >> 16);
+                    x[2] = (T)(int)(short)(d[1] & 0xffffu);
+                    x[3] = (T)((int)d[1] >> 16);
+                } else {
+                    int cL[4], cR[4];
+                    cL[0] = window_sample<3, 0, DW>(d), cR[0] = window_sample<3, 3, DW>(d);
+                    cL[1] = window_sample<3, 6, DW>(d), cR[1] = window_sample<3, 9, DW>(d);
+                    cL[2] = window_sample<3, 12, DW>(d), cR[2] = window_sample<3, 15, DW>(d);
+                    cL[3] = window_sample<3, 18, DW>(d), cR[3] = window_sample<3, 21, DW>(d);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // (the integer sum and difference of two 24-bit samples are exact)
+                        const int c = vv == 0 ? cL[i] : (vv == 1 ? cR[i] : (vv == 2 ? cL[i] + cR[i] : cL[i] - cR[i]));
+                        x[i] = vv == 2 ? (T)0.5 * (T)c : (T)c;
+                    }
+                }
+                T y1 = sub_mul_exact(x[1], x[0], preK);
+                const T y2 = sub_mul_exact(x[2], x[1], preK);
+                if (r == 0 && firstTile && fr == 0 && l == 0) y1 = x[1] * ((T)1 - preK); // s[1] *= 1 - k
+                if (a.zcFlag) {
+                    const T y3 = sub_mul_exact(x[3], x[2], preK);
+                    const int s0 = 2 * (l + G * r);
+                    const bool c01 = (y1 < 0 && y2 > 0) || (y1 > 0 && y2 < 0);
+                    const bool c12 = (y2 < 0 && y3 > 0) || (y2 > 0 && y3 < 0);
+                    zcn += (c01 && s0 + 1 < a.wlen) ? 1 : 0; // pairs inside the frame only
+                    zcn += (c12 && s0 + 2 < a.wlen) ? 1 : 0;
+                }
+                const cpx<T> w = winT[lq + G * r];
+                v[r] = cpx<T>{y1 * w.x, y2 * w.y};
+            }
+#pragma unroll
+            for (int r = NZ; r < PPL; ++r) v[r] = cpx<T>{0.0, 0.0};
+        }
+        T te = 0;
+        if (a.energyFlag) {
+            cpx<T> e2 = {0, 0};
+#pragma unroll
+            for (int r = 0; r < NZ; ++r) e2 += v[r] * v[r];
+            te = frame_sum<G>((T)4 * (e2.x + e2.y)); // (the window table holds half the Hamming values)
+        }
+        if (a.zcFlag) zcn = frame_sum<G>(zcn);
+        STAMP(1);
+
+        // ---- NC-point complex FFT of z[n] = x[2n] + i x[2n+1] (Realft mfcc.c:262-270): Stockham
+        //      stages of radix 16, 16 (and 4), real parts and imaginary parts exchanged in turn
+        Radix<T, 16>::run(v);
+        {
+            T *wp = Zt + 17 * l;                                 // zpad(16 l + r) = 17 l + r
+            const T *rp = Zt + l + (l >> 4);                     // zpad(l + G r) = zpad(l) + (G + G / 16) r
+            constexpr int RS = G + G / 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[r] = v[r].x;
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r].x = rp[RS * r];
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[r] = v[r].y;
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r].y = rp[RS * r];
+            wave_fence();
+        }
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], twT[(r - 1) * 16 + (lq & 15)]); // sub-transform size 16: [r-1][l mod 16]
+        Radix<T, 16>::run(v);
+        if constexpr (G == 64) {
+            const int o = ((l >> 4) << 8) + (l & 15);
+            T *wp = Zt + o + (o >> 4);                           // zpad(o + 16 r) = zpad(o) + 17 r
+            const T *rp = Zt + l + (l >> 4);                     // zpad(l + 64 b + 256 r) = zpad(l) + 68 b + 272 r
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[17 * r] = v[r].x;
+            wave_fence();
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * b + r].x = rp[68 * b + 272 * r];
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[17 * r] = v[r].y;
+            wave_fence();
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * b + r].y = rp[68 * b + 272 * r];
+            wave_fence();
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 1; r < 4; ++r) v[4 * b + r] = cmul(v[4 * b + r], twT[15 * 16 + (r - 1) * 256 + 64 * b + lq]); // size 256: [r-1][l + 64 b]
+#pragma unroll
+            for (int b = 0; b < 4; ++b) Radix<T, 4>::run(&v[4 * b]);
+        }
+        // the lane now holds X[l + G m], m = 0 .. 15, in register xr(m)
+        auto xr = [&](int m) -> cpx<T> & { return G == 16 ? v[m] : v[4 * (m & 3) + (m >> 2)]; };
+        STAMP(3);
+
+        // ---- real-FFT split and power (mfcc.c:274-290, ek of mfcc.c:153-155): the upper half of the
+        //      spectrum goes through the work area (complex index = bin - NC / 2) and the lane reads
+        //      back X[NC - l - G q], q = 0 .. 7 (lane 0, q = 0: one point past the bins, unused)
+        T pa[NPAIR], pb[NPAIR];
+        {
+#pragma unroll
+            for (int m = 8; m < 16; ++m) Zc[l + G * (m - 8)] = xr(m);
+            wave_fence();
+            cpx<T> rev[NPAIR];
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) rev[q] = Zc[NC / 2 - l - G * q];
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) split_power<T>(xr(q), rev[q], swT[lq + G * q], pa[q], pb[q]);
+            // bin 0 packs Re + Im of X[0] (mfcc.c:288-290); bin NC / 2 is |X[NC / 2]|^2; lane 0 holds both
+            const cpx<T> z0 = xr(0), zh = xr(8);
+            const T p0 = (T)4 * (z0.x + z0.y) * (z0.x + z0.y);
+            const T ph = (T)4 * (zh.x * zh.x + zh.y * zh.y);
+            pa[0] = l == 0 ? p0 : pa[0];
+            pb[0] = l == 0 ? ph : pb[0];
+        }
+        wave_fence(); // every lane has read its partner points: the area takes the power values, bin order
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            const int k = l + G * q;
+            const int k2 = k == 0 ? NC / 2 : NC - k;
+            Zt[k] = pa[q];
+            Zt[k2] = pb[q];
+        }
+        wave_fence();
+        STAMP(4);
+        if constexpr (LAST && !EARLY) {
+            if (nx.valid()) {
+                draw_step();
+                fetch(nx, pf);
+            }
+        }
+
+        // ---- sub-band energies / brightness (main.c:235-236): every band (the whole spectrum when
+        //      only the brightness is asked for) gets a power-of-two share of the frame's lanes
+        if (F_S > 0 || a.brightFlag) {
+            const int nseg = F_S > 0 ? F_S : 1, width = NC / nseg;
+            int lpb = 1;
+            while (lpb * 2 * nseg <= G) lpb *= 2;
+            const int perPass = G / lpb;
+            for (int b0 = 0; b0 < nseg; b0 += perPass) {
+                const int b = b0 + l / lpb, sl = l & (lpb - 1);
+                T e = 0, ek = 0;
+                if (b < nseg) {
+                    const int lo = b * width, hi = (b == nseg - 1) ? NC : lo + width;
+                    for (int k = lo + sl; k < hi; k += 4 * lpb) { // four reads in flight
+                        T pv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pv[i] = Zt[min(k + i * lpb, NC - 1)];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool in = k + i * lpb < hi;
+                            e += in ? pv[i] : (T)0;
+                            ek += in ? (T)(k + i * lpb + 1) * pv[i] : (T)0;
+                        }
+                    }
+                }
+                for (int o = lpb >> 1; o > 0; o >>= 1) {
+                    e += __shfl_xor(e, o, 64);
+                    ek += __shfl_xor(ek, o, 64);
+                }
+                // the band's two sums are parked behind the bins (2 nseg <= NC / 16 values)
+                if (b < nseg && sl == 0) {
+                    Zt[NC + b] = e;
+                    Zt[NC + nseg + b] = ek;
+                }
+            }
+            wave_fence();
+            T total = 0, num = 0;
+            for (int g = 0; g < nseg; ++g) {
+                total += Zt[NC + g];
+                num += Zt[NC + nseg + g];
+            }
+            if (live) {
+                if (F_S > 0)
+                    for (int b = l; b < nseg; b += G) fo[subAt + b] = Zt[NC + b] / total;
+                if (a.brightFlag && l == 0) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / total / (T)NC;
+            }
+        }
+        if (live && l == 0) {
+            if (a.energyFlag) fo[a.M + a.c0Flag] = tlog<T>(te);                                  // main.c:243
+            if (a.zcFlag) fo[a.M + a.c0Flag + a.energyFlag] = (T)zcn / (T)(a.wlen - 1);           // main.c:244
+        }
+        STAMP(5);
+
+        // ---- mel filterbank (mfcc.c:152-163): the bins whose lower channel is c form one segment,
+        //      cut by the host into parts; a lane sums Tc = sum loWt p and Uc = sum (p - loWt p) of its
+        //      parts in bin order, the part sums go to the work area, and the lane of channel b adds the
+        //      parts of U[b-1] and of T[b] in part (= bin) order; then log(max(., 1)) (mfcc.c:171-176)
+        T ps[NPL][2];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            T accT = 0, accU = 0;
+            for (int k = partB[j]; k < partE[j]; k += 4) {
+                T pv[4], wv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pv[i] = Zt[k + i]; // (reads past the part stay inside the area / the weight table's zero tail)
+                    wv[i] = lwL[k + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool in = k + i < partE[j];
+                    const T t1 = wv[i] * pv[i];
+                    accT += in ? t1 : (T)0;
+                    accU += in ? pv[i] - t1 : (T)0;
+                }
+            }
+            ps[j][0] = accT;
+            ps[j][1] = accU;
+        }
+        wave_fence(); // every part has been read: the bins' place takes the part sums
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            Zt[l + G * j] = ps[j][0];
+            Zt[kPipeParts + l + G * j] = ps[j][1];
+        }
+        wave_fence();
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) {
+            const int ch = l + G * j;
+            const int4 cp = chanParts[j];
+            T pu[10], pt[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                pu[i] = Zt[kPipeParts + cp.x + i];
+                pt[i] = Zt[cp.z + i];
+            }
+            T mu = 0, mt = 0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                mu += i < cp.y ? pu[i] : (T)0;
+                mt += i < cp.w ? pt[i] : (T)0;
+            }
+            const T m = mu + mt;
+            const T lv = tlog<T>(m < (T)1 ? (T)1 : m);
+            if (ch < a.P) {
+                if (a.fbankFlag) {
+                    if (live) fo[ch] = lv;
+                } else if constexpr (G == 16) {
+                    lvr[j] = lv;
+                } else {
+                    lvr[0] = vv == 0 ? lv : lvr[0];
+                    lvr[1] = vv == 1 ? lv : lvr[1];
+                    lvr[2] = vv == 2 ? lv : lvr[2];
+                    lvr[3] = vv == 3 ? lv : lvr[3];
+                }
+            }
+        }
+        wave_fence(); // the work area is free again
+        STAMP(6);
+        if constexpr (LAST) {
+            // every row of the tile has expanded its samples: the next tile's bytes take their place
+            if (nx.valid()) store_raw(nx, pf);
+            if (!a.fbankFlag) {
+                // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208): the tile's
+                //      log-mel values go to the work area as [channel][row]; lane j of a frame forms
+                //      coefficient j of every row from its table row (row M is all ones: C0)
+                auto cepstra = [&](auto rowsTag) {
+                    constexpr int VV = decltype(rowsTag)::value;
+                    if constexpr (G == 16) {
+#pragma unroll
+                        for (int j = 0; j < CHL; ++j)
+                            if (l + G * j < a.P) Zt[l + G * j] = lvr[j];
+                    } else {
+                        if (l < a.P) {
+#pragma unroll
+                            for (int vq = 0; vq < VV; ++vq) Zt[l * VV + vq] = lvr[vq];
+                        }
+                    }
+                    wave_fence();
+                    T *orow = a.out + ((long long)cur.outRow + fr) * a.step;
+                    for (int j0 = 0; j0 < JW; j0 += G) {
+                        const int j = j0 + l;
+                        const T *row = dctT + (j < JW ? j : JW - 1) * a.dctPitch;
+                        T acc[VV];
+#pragma unroll
+                        for (int vq = 0; vq < VV; ++vq) acc[vq] = 0;
+                        for (int k0 = 0; k0 < a.P; k0 += 4) {
+                            T tv[4], f[4][VV];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int k = min(k0 + u, a.P - 1);
+                                tv[u] = k0 + u < a.P ? row[k] : (T)0;
+#pragma unroll
+                                for (int vq = 0; vq < VV; ++vq) f[u][vq] = Zt[k * VV + vq];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int vq = 0; vq < VV; ++vq) acc[vq] += tv[u] * f[u][vq];
+                        }
+                        if (j < JW && live) {
+#pragma unroll
+                            for (int vq = 0; vq < VV; ++vq) orow[vq * a.D + j] = acc[vq] * a.mfnorm;
+                        }
+                    }
+                };
+                switch (F_V) {
+                case 1: cepstra(std::integral_constant<int, 1>{}); break;
+                case 2: cepstra(std::integral_constant<int, 2>{}); break;
+                case 3: cepstra(std::integral_constant<int, 3>{}); break;
+                default: cepstra(std::integral_constant<int, 4>{}); break;
+                }
+            }
+            wave_fence(); // the raw bytes are in place, the work area is free
+        }
+        STAMP(9);
+    };
+    for (;;) {
+        // the descriptor three tiles ahead: asked for now, moved into place at the tile's end
+        const int id3 = next_tile_s();
+        const PipeTile d3 = pipe_desc(tab, id3 < 0 ? 0 : id3, id3 >= 0);
+        for (int vv = 0; vv + 1 < F_V; ++vv) round(vv, std::false_type{});
+        round(F_V - 1, std::true_type{});
+        if (!nx.valid()) break;
+        cur = nx;
+        nx = nn;
+        nn = d3;
+    }
+    asm volatile("" ::"v"(warm0), "v"(warm1));
+    finish();
+    STAMP_FLUSH;
+}
+
+// ------------------------------------------------------------------------------------------
+// Geometry the host plans with.
+// ------------------------------------------------------------------------------------------
+
+// 0: the kernel does not take this input class; else log2 of the complex points (8 or 10)
+int pipe64_class(int log2nc, int channels, int bps, int wlen, int inc)
+{
+    if (log2nc == 8 && channels == 1 && bps == 2 && inc % 2 == 0 && wlen >= 8) {
+        // the fetch of a full tile (4 frames and the predecessor) must fit 2 vectors per lane
+        const long bytes = ((long)3 * inc + wlen + 1) * 2;
+        return bytes <= 2 * 64 * 16 ? 8 : 0;
+    }
+    if (log2nc == 10 && channels == 2 && bps == 3 && wlen > 1024) {
+        const long bytes = ((long)wlen + 1) * 6;
+        return bytes <= 11 * 64 * 16 ? 10 : 0;
+    }
+    return 0;
+}
+int pipe64_waves() { return kPipeWaves; }
+int pipe64_frames_per_tile(int cls) { return cls == 8 ? 4 : 1; }
+int pipe64_lanes(int cls) { return cls == 8 ? 16 : 64; }
+int pipe64_nz(int cls, int wlen)
+{
+    const int per = cls == 8 ? 32 : 128; // samples per first-stage input index
+    const int nz = (wlen + per - 1) / per;
+    return cls == 8 ? (nz <= 13 ? 13 : 16) : (nz <= 14 ? 14 : 16);
+}
+// LDS bytes of one wave's raw PCM area: the tile's bytes.  (A lane also reads the instants behind
+// the frame's last sample up to the end of its first-stage inputs, where the window is zero: those
+// reads may run into the wave's own work area, which follows the raw bytes and is larger.)
+int pipe64_raw_bytes(int cls, int wlen, int inc)
+{
+    const int gt = pipe64_frames_per_tile(cls), bpi = cls == 8 ? 2 : 6;
+    const long tile = ((long)(gt - 1) * inc + wlen + 1) * bpi;
+    return (int)((tile + 15 + 16) & ~15L);
+}
+int pipe64_area_elems(int cls) { return (1 << cls) + (1 << cls) / 16; }
+// shared tables in front of the waves' regions, in doubles
+int pipe64_tab_elems(int cls, int wlen, int dctElems)
+{
+    const int nc = 1 << cls;
+    int n = nc + 8;
+    if (cls == 8) n += 2 * (pipe64_nz(cls, wlen) * 16 + 15 * 16 + nc / 2) + dctElems;
+    return (n + 1) & ~1;
+}
+
+template <int LOG2NC, int CH, int BPS, int NZ>
+static int launch_pipe_t(const FrontArgs<double> &a, int numBlocks, size_t lds, hipStream_t st)
+{
+    static std::atomic<bool> attrSet[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64 || !attrSet[dev].load(std::memory_order_acquire)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pipe64<LOG2NC, CH, BPS, NZ>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0 && dev < 64) attrSet[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_pipe64<LOG2NC, CH, BPS, NZ>), dim3(numBlocks), dim3(kPipeWaves * 64), lds, st, a);
+    return (int)hipGetLastError();
+}
+
+int launch_pipe64(const FrontArgs<double> &a, int cls, int numBlocks, size_t lds, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nz = pipe64_nz(cls, a.wlen);
+    if (cls == 8) return nz == 13 ? launch_pipe_t<8, 1, 2, 13>(a, numBlocks, lds, st) : launch_pipe_t<8, 1, 2, 16>(a, numBlocks, lds, st);
+    return nz == 14 ? launch_pipe_t<10, 2, 3, 14>(a, numBlocks, lds, st) : launch_pipe_t<10, 2, 3, 16>(a, numBlocks, lds, st);
+}
+
+} // namespace mfcc

@@ -133,8 +133,11 @@ def test_lean_kernel_modes(oracle, wlen, bank, cepstral):
     pcm = _pcm(n, 1, 2, wlen + bank, 16000, tone=0)
     ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
     assert ref.shape[0] == 37
-    got = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], 1, 2)[0]
-    _compare(got, ref, kw, False)
+    # (double precision: frames of at most 512 samples take the pipelined double-precision kernel)
+    for f64 in (False, True):
+        cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+        got = run_product_batch(ma, cfg, [pcm.tobytes()], 1, 2)[0]
+        _compare(got, ref, kw, f64)
 
 
 @pytest.mark.parametrize("wlen,bank,vec", [(1025, 8, 1), (1100, 64, 2), (1153, 23, 3), (1500, 40, 4), (1665, 3, 2),
@@ -155,11 +158,13 @@ def test_stereo_2048_point_kernel_modes(oracle, wlen, bank, vec, cepstral, extra
               zeroCrossingFlag=1 if extras else 0, brightFlag=1 if extras else 0,
               subBandEFlag=(8 if bank % 2 else 5) if extras else 0)
     pcms = [_pcm(wlen + k * inc + 7, 2, 3, wlen + bank + k, 44100, tone=0) for k in (9, 1, 0)]
-    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
-    got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 2, 3, pad=3)
-    for g, p in zip(got, pcms):
-        ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), p, 2, 3)
-        _compare(g, ref, kw, False)
+    refs = [oracle.extract_pcm_bytes(oracle.make_config(**kw), p, 2, 3) for p in pcms]
+    # (both precisions have a one-wave-per-frame kernel for this class)
+    for f64 in (False, True):
+        cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+        got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 2, 3, pad=3)
+        for g, ref in zip(got, refs):
+            _compare(g, ref, kw, f64)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MFCC_FUZZ_SEEDS", "48"))))
