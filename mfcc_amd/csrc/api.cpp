@@ -101,6 +101,9 @@ struct MFCCPlan {
     int leanWaves = 0;    // ... with this many waves per workgroup
     int leanChunk = 0;    // ... tiles per chunk override (0: heuristic, -1: fixed ranges)
     std::vector<float> melW;
+    std::vector<double> melW64; // k_pipe64's matrix-core filterbank (256-point class)
+    double *dMelW64 = nullptr;
+    int melSlotSteps[4] = {0, 0, 0, 0};
     std::vector<int32_t> melMeta;
     int melSteps = 0;
     float *dMelW = nullptr;
@@ -342,6 +345,100 @@ static bool pipe64_part_table(MFCCPlan *p, int cls, bool debug)
     return true;
 }
 
+// k_pipe64, 256-point class: the mel filterbank (mfcc.c:152-163) of a wave's four frames as
+// 4 x 4 x 4 double-precision matrix-core products.  Channels are taken in quads; a quad's bins are
+// those of the segments that reach its channels.  The instruction works on four independent blocks
+// (lane / 4 % 4), so four quads are worked on at a time: a "slot".  Quads are dealt to (slot, block)
+// by descending run length; a slot takes as many steps of 4 bins as its longest run needs.  Lane
+// (j, blk, k) = (lane % 4, lane / 4 % 4, lane / 16) reads the power of frame j at bin
+// r0[blk] + 4 t + k; the four frames' values sit 264 doubles apart, 8 LDS banks, so the 32 lanes
+// of one LDS pass hit 32 different 8-byte bank pairs when the blocks' r0 are 0, 2, 4, 6 modulo 8
+// in some order: the order with the fewest steps is taken.  Tables: weights [step][lane]; per lane
+// and slot {element offset of its power operand inside the wave's work areas, channel of its result
+// or -1}.  false: too many quads or steps.
+static bool pipe64_mel_matrix(MFCCPlan *p, bool debug)
+{
+    const MFCCContext *c = p->ctx;
+    const int P = c->cfg.bankNum, nc = c->tab.nc, NQ = (P + 3) / 4;
+    if (NQ > 16) return false;
+    std::vector<int> sb(P + 1, 0), se(P + 1, 0);
+    for (int k = 0; k < nc; ++k) {
+        const int ch = c->tab.loChan[k];
+        if (ch < 0 || ch > P) continue;
+        if (se[ch] == 0) sb[ch] = k;
+        se[ch] = k + 1;
+    }
+    std::vector<int> q0(NQ, 0), q1(NQ, 0), order(NQ);
+    for (int q = 0; q < NQ; ++q) {
+        int k0 = nc, k1 = 0;
+        for (int sIdx = 4 * q; sIdx <= std::min(4 * q + 4, P); ++sIdx)
+            if (se[sIdx] > sb[sIdx]) k0 = std::min(k0, sb[sIdx]), k1 = std::max(k1, se[sIdx]);
+        if (k1 < k0) k0 = k1 = 0;
+        q0[q] = k0, q1[q] = k1;
+        order[q] = q;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return q1[x] - q0[x] > q1[y] - q0[y]; });
+    int quadOf[4][4], r0[4][4], total = 0;
+    for (int sl = 0; sl < 4; ++sl) {
+        p->melSlotSteps[sl] = 0;
+        for (int b = 0; b < 4; ++b) quadOf[sl][b] = sl * 4 + b < NQ ? order[sl * 4 + b] : -1, r0[sl][b] = 2 * b;
+        if (sl * 4 >= NQ) continue;
+        int perm[4] = {0, 1, 2, 3}, best = 0, bestPerm[4] = {0, 1, 2, 3};
+        auto start_of = [&](int b, int res) { // largest start <= the run's first bin with start = res (mod 8)
+            const int q = quadOf[sl][b];
+            if (q < 0) return res;
+            return q0[q] - (((q0[q] - res) % 8 + 8) % 8);
+        };
+        do {
+            int steps = 1;
+            for (int b = 0; b < 4; ++b)
+                if (quadOf[sl][b] >= 0) steps = std::max(steps, (q1[quadOf[sl][b]] - start_of(b, 2 * perm[b]) + 3) / 4);
+            if (!best || steps < best) {
+                best = steps;
+                std::copy(perm, perm + 4, bestPerm);
+            }
+        } while (std::next_permutation(perm, perm + 4));
+        p->melSlotSteps[sl] = best;
+        for (int b = 0; b < 4; ++b) {
+            int st = start_of(b, 2 * bestPerm[b]);
+            // every read stays inside the wave's work areas: start + 4 steps <= 280 (the last frame's
+            // values begin at element 800 of 1088)
+            while (st + 4 * best > 280) st -= 8;
+            if (st < -8) return false;
+            r0[sl][b] = st;
+        }
+        total += best;
+    }
+    if (total > 96) return false;
+    p->melSteps = total;
+    p->melW64.assign((size_t)total * 64, 0.0);
+    p->melMeta.assign(64 * 8, 0);
+    int tbase = 0;
+    for (int sl = 0; sl < 4; ++sl) {
+        for (int ln = 0; ln < 64; ++ln) {
+            const int j = ln & 3, blk = (ln >> 2) & 3, k = ln >> 4;
+            const int q = quadOf[sl][blk], ch = q >= 0 ? 4 * q + j : -1;
+            p->melMeta[8 * ln + 2 * sl] = 8 + j * 264 + r0[sl][blk] + k;
+            p->melMeta[8 * ln + 2 * sl + 1] = (ch >= 0 && ch < P) ? ch : -1;
+            if (ch < 0 || ch >= P) continue;
+            for (int t = 0; t < p->melSlotSteps[sl]; ++t) {
+                const int bin = r0[sl][blk] + 4 * t + k;
+                if (bin < q0[q] || bin >= q1[q] || bin < 0 || bin >= nc) continue;
+                const int sIdx = c->tab.loChan[bin]; // mfcc.c:158-163: loWt to channel sIdx - 1, the rest to channel sIdx (0-based)
+                double w = 0.0;
+                if (sIdx == ch + 1) w = c->tab.loWt[bin];
+                if (sIdx == ch) w = 1.0 - c->tab.loWt[bin];
+                p->melW64[(size_t)(tbase + t) * 64 + ln] = w;
+            }
+        }
+        tbase += p->melSlotSteps[sl];
+    }
+    if (debug)
+        fprintf(stderr, "mfcc plan: matrix-core mel (double), %d steps of 4 bins in slots of %d / %d / %d / %d\n", total, p->melSlotSteps[0],
+                p->melSlotSteps[1], p->melSlotSteps[2], p->melSlotSteps[3]);
+    return true;
+}
+
 // LDS geometry of the static-feature kernel for this plan: frames per tile, whether the window /
 // twiddle / split tables get an LDS copy, and how many workgroups fit a CU.
 static int choose_tile(MFCCPlan *p, bool allowWide = true)
@@ -367,7 +464,7 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
     // double precision, one of the two benchmark input classes: k_pipe64 (raw PCM bytes in LDS, wave-sized teams)
     const int pipeCls = (plainFbank && allowWide && prec == MFCC_PREC_F64 && !c->cfg.zeroMeanSigFlag && !c->cfg.fftLength &&
                          p->totalRows < 0x7fffffffLL && !tune.noLean && c->cfg.bankNum <= 64 &&
-                         2 * std::max(c->cfg.subBandEFlag, 1) <= nc / 16)
+                         c->cfg.subBandEFlag <= nc / 16)
                             ? pipe64_class(log2nc, p->channels, p->bps, c->cfg.wlen, c->cfg.inc)
                             : 0;
     int pplog = (front_variant_exists(log2nc, 3) && !leanCand && !wideCand && !pipeCls) ? 3 : 4;
@@ -692,9 +789,11 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
         const int rawEl = pipe64_raw_bytes(pipeCls, c->cfg.wlen, c->cfg.inc) / 8;
         const int gt = pipe64_frames_per_tile(pipeCls);
         const int teamL = rawEl + gt * pipe64_area_elems(pipeCls);
-        const int tabL = pipe64_tab_elems(pipeCls, c->cfg.wlen, c->dctElems);
+        p->melSteps = 0;
+        if (!(pipeCls == 8 ? pipe64_mel_matrix(p, tune.debug != 0) : pipe64_part_table(p, pipeCls, tune.debug != 0))) return choose_tile(p, false);
+        const int tabL = pipe64_tab_elems(pipeCls, c->cfg.wlen, c->dctElems, p->melSteps);
         const size_t bytes = ((size_t)tabL + (size_t)pipe64_waves() * teamL) * sizeof(double);
-        if (bytes > kLds || !pipe64_part_table(p, pipeCls, tune.debug != 0)) return choose_tile(p, false);
+        if (bytes > kLds) return choose_tile(p, false);
         p->pipe64 = pipeCls;
         p->framesPerTile = gt;
         p->rowPitch = rawEl;
@@ -958,6 +1057,12 @@ static int finish_plan(MFCCPlan *p)
         HIP_TRY(hipMalloc((void **)&p->dWork, 2 * sizeof(unsigned)));
         HIP_TRY(hipMemset(p->dWork, 0, 2 * sizeof(unsigned)));
     }
+    if (p->pipe64 == 8) {
+        HIP_TRY(hipMalloc((void **)&p->dMelW64, p->melW64.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(p->dMelW64, p->melW64.data(), p->melW64.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&p->dMelMeta, p->melMeta.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(p->dMelMeta, p->melMeta.data(), p->melMeta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     if (p->mode == 2) {
         HIP_TRY(hipMalloc((void **)&p->dMelW, p->melW.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(p->dMelW, p->melW.data(), p->melW.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1155,6 +1260,7 @@ extern "C" void MFCCPlanDestroy(MFCCPlan *p)
     (void)hipFree(p->dTiles);
     (void)hipFree(p->dRegUtt);
     (void)hipFree(p->dMelW);
+    (void)hipFree(p->dMelW64);
     (void)hipFree(p->dBlockPartial);
     (void)hipFree(p->dStatics);
     (void)hipFree(p->dMelMeta);
@@ -1224,6 +1330,8 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
     a.melW = p->dMelW;
     a.melMeta = p->dMelMeta;
     a.melSteps = p->melSteps;
+    a.melW64 = p->dMelW64;
+    for (int sl = 0; sl < 4; ++sl) a.melSlotSteps[sl] = p->melSlotSteps[sl];
     a.out = static_cast<T *>(outDev);
     a.numTiles = p->numTiles;
     a.wlen = c->cfg.wlen;

@@ -53,6 +53,8 @@ struct FrontArgs {
     const int32_t *melMeta;   // mode 2: 64 x {first bin of the lane's block, flags (1 / 4 / 8: add the block
                               // one / two / three before, 2: writes results), channel or -1, 0}
     int melSteps;
+    const double *melW64;     // k_pipe64, 256-point class: melSteps x 64 weights of the 4 x 4 x 4 matrix-core filterbank
+    int melSlotSteps[4];      // ... steps of each of its four slots (a slot: four quads of channels at a time)
     T *out;
     int numTiles;
     int numUtts;              // entries of utts (k_lean256 walks them)
@@ -169,7 +171,7 @@ int pipe64_frames_per_tile(int cls);
 int pipe64_lanes(int cls);                // lanes that share one frame
 int pipe64_raw_bytes(int cls, int wlen, int inc); // LDS bytes a wave reserves for a tile's raw PCM
 int pipe64_area_elems(int cls);           // doubles per frame work area
-int pipe64_tab_elems(int cls, int wlen, int dctElems); // doubles of the shared tables in LDS
+int pipe64_tab_elems(int cls, int wlen, int dctElems, int melSteps); // doubles of the shared tables in LDS
 int launch_pipe64(const FrontArgs<double> &a, int cls, int numBlocks, size_t ldsBytes, void *stream);
 bool front_variant_exists(int log2nc, int pplog); // pplog: log2 of complex points per lane (4, 3, 2)
 int front_groups(int log2nc, int pplog);          // frames in flight per workgroup

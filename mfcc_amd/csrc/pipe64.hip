@@ -72,6 +72,36 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ln x for x = 0 (-inf) or a finite normal x > 0 (what the filterbank sums, floored at 1, and the
+// frame energies of integer samples are): x = 2^e m with m in [sqrt 1/2, sqrt 2], ln m = 2 atanh s,
+// s = (m - 1) / (m + 1), |s| < 0.1716, as its series up to s^21 (remainder < 2e-17); e ln 2 in two
+// parts.  Error below 1e-15 relative, a fifth of the library routine's instructions.
+__device__ __forceinline__ double fast_log(double x)
+{
+    const long long bits = __double_as_longlong(x);
+    int e = (int)(bits >> 52) - 1023;
+    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    const bool big = m > 1.4142135623730951;
+    m = big ? 0.5 * m : m;
+    e += big ? 1 : 0;
+    const double sq = (m - 1.0) / (m + 1.0), z = sq * sq;
+    double pl = 1.0 / 21.0;
+    pl = pl * z + 1.0 / 19.0;
+    pl = pl * z + 1.0 / 17.0;
+    pl = pl * z + 1.0 / 15.0;
+    pl = pl * z + 1.0 / 13.0;
+    pl = pl * z + 1.0 / 11.0;
+    pl = pl * z + 1.0 / 9.0;
+    pl = pl * z + 1.0 / 7.0;
+    pl = pl * z + 1.0 / 5.0;
+    pl = pl * z + 1.0 / 3.0;
+    pl = pl * z; // ln m = 2 s (1 + pl)
+    const double ed = (double)e, s2 = sq + sq;
+    const double ln2hi = 0x1.62e42fee00000p-1, ln2lo = 0x1.a39ef35793c76p-33; // ln2hi: 32 significant bits, e ln2hi is exact
+    const double r = ed * ln2hi + (s2 + (s2 * pl + ed * ln2lo));
+    return x == 0.0 ? -__builtin_huge_val() : r;
+}
+
 // sum over the G lanes of a frame (G = 16: one row of lanes, G = 64: the wave)
 template <int G>
 __device__ __forceinline__ double frame_sum(double v)
@@ -99,6 +129,8 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
     constexpr bool EARLY = PFN <= 2;       // the next tile's bytes are requested at the start of the round
     constexpr int ZP = NC + NC / 16;       // doubles per work area
     constexpr int DW = G == 16 ? 2 : 6;    // dwords a lane reads per sample pair: instants 2n-1 .. 2n+2
+    constexpr bool MELM = G == 16;         // mel filterbank of the wave's four frames on the matrix cores
+    constexpr int PP = 264;                // MELM: doubles between the four frames' power values (8 LDS banks apart)
     typedef double T;
     STAMP_DECL
     STAMP_START;
@@ -107,20 +139,30 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
     const int tt = tid & 63;
     const int l = tt & (G - 1), grp = tt / G;
 
-    // LDS: [filterbank weights (NC + 8) | TABLDS: window pairs (NZ G) | twiddles (15 x 16) | split
-    // factors (NC / 2) | cepstral table] then one region per wave: [raw PCM bytes | GT work areas]
+    // LDS: [filterbank weights (NC + 8, or the matrix-core table of melSteps x 64) | TABLDS: window
+    // pairs (NZ G) | twiddles (15 x 16) | split factors (NC / 2) | cepstral table] then one region
+    // per wave: [raw PCM bytes | GT work areas]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *lwL = reinterpret_cast<T *>(smem);
-    cpx<T> *winL = reinterpret_cast<cpx<T> *>(lwL + NC + 8);
+    const int lwN = MELM ? a.melSteps * 64 : NC + 8;
+    cpx<T> *winL = reinterpret_cast<cpx<T> *>(lwL + lwN);
     cpx<T> *twL = winL + NZ * G;
     cpx<T> *swL = twL + 15 * 16;
     T *dctL = reinterpret_cast<T *>(swL + NC / 2);
     unsigned char *region = smem + ((size_t)a.tabElems + (size_t)wave * a.teamElems) * sizeof(T);
     unsigned *raw = reinterpret_cast<unsigned *>(region);
-    T *Zt = reinterpret_cast<T *>(region) + a.rowPitch + grp * ZP; // (rowPitch: elements reserved for the raw bytes)
+    T *areasW = reinterpret_cast<T *>(region) + a.rowPitch; // (rowPitch: elements reserved for the raw bytes)
+    T *Zt = areasW + grp * ZP;
     cpx<T> *Zc = reinterpret_cast<cpx<T> *>(Zt);
+    // power values of the lane's frame, bin order: its own work area, or (MELM) 8 elements into
+    // the wave's areas and PP apart, so that the four frames' values at one bin sit 8 banks apart
+    T *Pw = MELM ? areasW + 8 + grp * PP : Zt;
 
-    for (int i = tid; i < NC + 8; i += WAVES * 64) lwL[i] = i < NC ? a.loWt[i] : (T)0;
+    if constexpr (MELM) {
+        for (int i = tid; i < lwN; i += WAVES * 64) lwL[i] = a.melW64[i];
+    } else {
+        for (int i = tid; i < NC + 8; i += WAVES * 64) lwL[i] = i < NC ? a.loWt[i] : (T)0;
+    }
     if constexpr (TABLDS) {
         for (int i = tid; i < NZ * G; i += WAVES * 64) winL[i] = reinterpret_cast<const cpx<T> *>(a.window)[i];
         for (int i = tid; i < 15 * 16; i += WAVES * 64) twL[i] = reinterpret_cast<const cpx<T> *>(a.tw)[i];
@@ -128,27 +170,36 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         for (int i = tid; i < a.dctElems; i += WAVES * 64) dctL[i] = a.dctT[i];
     }
     // every value a masked sum may read from a work area is a finite number from here on
-    for (int i = l; i < ZP; i += G) Zt[i] = (T)0;
+    for (int i = tt; i < GT * ZP; i += 64) areasW[i] = (T)0;
     __syncthreads();
     const cpx<T> *winT = TABLDS ? winL : reinterpret_cast<const cpx<T> *>(a.window);
     const cpx<T> *twT = TABLDS ? twL : reinterpret_cast<const cpx<T> *>(a.tw);
     const cpx<T> *swT = TABLDS ? swL : reinterpret_cast<const cpx<T> *>(a.splitTw);
     const T *dctT = TABLDS ? dctL : a.dctT;
 
-    // mel segment parts of the lane and the part ranges of its channels (see pipe64 tables, api.cpp)
+    // !MELM: mel segment parts of the lane and the part ranges of its channels; MELM: per slot of
+    // the matrix-core filterbank, where the lane reads its power operand (element offset into the
+    // wave's areas) and which channel its result belongs to (see the pipe64 tables, api.cpp)
     const int4 *lseg = reinterpret_cast<const int4 *>(a.laneSeg);
     int partB[NPL], partE[NPL];
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-        const int4 e = lseg[l + G * j];
-        partB[j] = e.x;
-        partE[j] = e.z >= 0 ? e.y : e.x;
-    }
     int4 chanParts[CHL];
+    int melOff[4], melChan[4];
+    if constexpr (MELM) {
+        const int4 m0 = reinterpret_cast<const int4 *>(a.melMeta)[2 * tt], m1 = reinterpret_cast<const int4 *>(a.melMeta)[2 * tt + 1];
+        melOff[0] = m0.x, melChan[0] = m0.y, melOff[1] = m0.z, melChan[1] = m0.w;
+        melOff[2] = m1.x, melChan[2] = m1.y, melOff[3] = m1.z, melChan[3] = m1.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < CHL; ++j) {
-        const int ch = l + G * j;
-        chanParts[j] = ch < a.P ? lseg[kPipeParts + ch] : make_int4(0, 0, 0, 0);
+        for (int j = 0; j < NPL; ++j) {
+            const int4 e = lseg[l + G * j];
+            partB[j] = e.x;
+            partE[j] = e.z >= 0 ? e.y : e.x;
+        }
+#pragma unroll
+        for (int j = 0; j < CHL; ++j) {
+            const int ch = l + G * j;
+            chanParts[j] = ch < a.P ? lseg[kPipeParts + ch] : make_int4(0, 0, 0, 0);
+        }
     }
     const T preK = a.preK;
     const int JW = a.M + a.c0Flag;
@@ -432,8 +483,8 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         for (int q = 0; q < NPAIR; ++q) {
             const int k = l + G * q;
             const int k2 = k == 0 ? NC / 2 : NC - k;
-            Zt[k] = pa[q];
-            Zt[k2] = pb[q];
+            Pw[k] = pa[q];
+            Pw[k2] = pb[q];
         }
         wave_fence();
         STAMP(4);
@@ -447,51 +498,39 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         // ---- sub-band energies / brightness (main.c:235-236): every band (the whole spectrum when
         //      only the brightness is asked for) gets a power-of-two share of the frame's lanes
         if (F_S > 0 || a.brightFlag) {
-            const int nseg = F_S > 0 ? F_S : 1, width = NC / nseg;
+            const int nseg = F_S > 0 ? F_S : 1, width = NC / nseg; // (nseg <= G: one pass)
             int lpb = 1;
             while (lpb * 2 * nseg <= G) lpb *= 2;
-            const int perPass = G / lpb;
-            for (int b0 = 0; b0 < nseg; b0 += perPass) {
-                const int b = b0 + l / lpb, sl = l & (lpb - 1);
-                T e = 0, ek = 0;
-                if (b < nseg) {
-                    const int lo = b * width, hi = (b == nseg - 1) ? NC : lo + width;
-                    for (int k = lo + sl; k < hi; k += 4 * lpb) { // four reads in flight
-                        T pv[4];
+            const int b = l / lpb, sl = l & (lpb - 1);
+            T e = 0, ek = 0;
+            if (b < nseg) {
+                const int lo = b * width, hi = (b == nseg - 1) ? NC : lo + width;
+                for (int k = lo + sl; k < hi; k += 4 * lpb) { // four reads in flight
+                    T pv[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) pv[i] = Zt[min(k + i * lpb, NC - 1)];
+                    for (int i = 0; i < 4; ++i) pv[i] = Pw[min(k + i * lpb, NC - 1)];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const bool in = k + i * lpb < hi;
-                            e += in ? pv[i] : (T)0;
-                            ek += in ? (T)(k + i * lpb + 1) * pv[i] : (T)0;
-                        }
+                    for (int i = 0; i < 4; ++i) {
+                        const bool in = k + i * lpb < hi;
+                        e += in ? pv[i] : (T)0;
+                        ek += in ? (T)(k + i * lpb + 1) * pv[i] : (T)0;
                     }
                 }
-                for (int o = lpb >> 1; o > 0; o >>= 1) {
-                    e += __shfl_xor(e, o, 64);
-                    ek += __shfl_xor(ek, o, 64);
-                }
-                // the band's two sums are parked behind the bins (2 nseg <= NC / 16 values)
-                if (b < nseg && sl == 0) {
-                    Zt[NC + b] = e;
-                    Zt[NC + nseg + b] = ek;
-                }
             }
-            wave_fence();
-            T total = 0, num = 0;
-            for (int g = 0; g < nseg; ++g) {
-                total += Zt[NC + g];
-                num += Zt[NC + nseg + g];
+            for (int o = lpb >> 1; o > 0; o >>= 1) {
+                e += __shfl_xor(e, o, 64);
+                ek += __shfl_xor(ek, o, 64);
             }
+            // the band's sums sit in its first lane; totals over the frame's bands
+            const bool head = b < nseg && sl == 0;
+            const T total = frame_sum<G>(head ? e : (T)0), num = frame_sum<G>(head ? ek : (T)0);
             if (live) {
-                if (F_S > 0)
-                    for (int b = l; b < nseg; b += G) fo[subAt + b] = Zt[NC + b] / total;
+                if (F_S > 0 && head) fo[subAt + b] = e / total;
                 if (a.brightFlag && l == 0) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / total / (T)NC;
             }
         }
         if (live && l == 0) {
-            if (a.energyFlag) fo[a.M + a.c0Flag] = tlog<T>(te);                                  // main.c:243
+            if (a.energyFlag) fo[a.M + a.c0Flag] = fast_log(te);                                  // main.c:243
             if (a.zcFlag) fo[a.M + a.c0Flag + a.energyFlag] = (T)zcn / (T)(a.wlen - 1);           // main.c:244
         }
         STAMP(5);
@@ -500,6 +539,47 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         //      cut by the host into parts; a lane sums Tc = sum loWt p and Uc = sum (p - loWt p) of its
         //      parts in bin order, the part sums go to the work area, and the lane of channel b adds the
         //      parts of U[b-1] and of T[b] in part (= bin) order; then log(max(., 1)) (mfcc.c:171-176)
+        if constexpr (MELM) {
+            // matrix-core form: 4 x 4 x 4 products (frame x channel of a quad x bin), four quads at a
+            // time (one per block of 16 result lanes ... see the table builder); lane (j, blk, k) =
+            // (lane % 4, lane / 4 % 4, lane / 16) feeds the power of frame j at the block's bin
+            // r0 + 4 t + k and the weight of that bin for channel j of the block's quad, and receives
+            // the sum of frame lane / 16 (its own) for channel lane % 4 of that quad
+            int tbase = 0;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int L = a.melSlotSteps[sl];
+                if (L > 0) {
+                    const T *ap = areasW + melOff[sl];
+                    const T *bp = lwL + tbase * 64 + tt;
+                    T acc0 = 0, acc1 = 0;
+                    int t = 0;
+                    for (; t + 4 <= L; t += 4) {
+                        T av[4], bv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            av[i] = ap[4 * (t + i)];
+                            bv[i] = bp[64 * (t + i)];
+                        }
+                        acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av[0], bv[0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av[1], bv[1], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av[2], bv[2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av[3], bv[3], acc1, 0, 0, 0);
+                    }
+                    for (; t < L; ++t) acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[4 * t], bp[64 * t], acc0, 0, 0, 0);
+                    const T m = acc0 + acc1;
+                    const T lv = fast_log(m < (T)1 ? (T)1 : m);
+                    if (melChan[sl] >= 0) {
+                        if (a.fbankFlag) {
+                            if (live) fo[melChan[sl]] = lv;
+                        } else {
+                            lvr[sl] = lv;
+                        }
+                    }
+                    tbase += L;
+                }
+            }
+        } else {
         T ps[NPL][2];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
@@ -546,12 +626,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
                 mt += i < cp.w ? pt[i] : (T)0;
             }
             const T m = mu + mt;
-            const T lv = tlog<T>(m < (T)1 ? (T)1 : m);
+            const T lv = fast_log(m < (T)1 ? (T)1 : m);
             if (ch < a.P) {
                 if (a.fbankFlag) {
                     if (live) fo[ch] = lv;
-                } else if constexpr (G == 16) {
-                    lvr[j] = lv;
                 } else {
                     lvr[0] = vv == 0 ? lv : lvr[0];
                     lvr[1] = vv == 1 ? lv : lvr[1];
@@ -559,6 +637,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
                     lvr[3] = vv == 3 ? lv : lvr[3];
                 }
             }
+        }
         }
         wave_fence(); // the work area is free again
         STAMP(6);
@@ -571,10 +650,10 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
                 //      coefficient j of every row from its table row (row M is all ones: C0)
                 auto cepstra = [&](auto rowsTag) {
                     constexpr int VV = decltype(rowsTag)::value;
-                    if constexpr (G == 16) {
+                    if constexpr (MELM) {
 #pragma unroll
-                        for (int j = 0; j < CHL; ++j)
-                            if (l + G * j < a.P) Zt[l + G * j] = lvr[j];
+                        for (int sl = 0; sl < 4; ++sl)
+                            if (melChan[sl] >= 0 && a.melSlotSteps[sl] > 0) Zt[melChan[sl]] = lvr[sl];
                     } else {
                         if (l < a.P) {
 #pragma unroll
@@ -674,10 +753,10 @@ int pipe64_raw_bytes(int cls, int wlen, int inc)
 }
 int pipe64_area_elems(int cls) { return (1 << cls) + (1 << cls) / 16; }
 // shared tables in front of the waves' regions, in doubles
-int pipe64_tab_elems(int cls, int wlen, int dctElems)
+int pipe64_tab_elems(int cls, int wlen, int dctElems, int melSteps)
 {
     const int nc = 1 << cls;
-    int n = nc + 8;
+    int n = cls == 8 ? melSteps * 64 : nc + 8;
     if (cls == 8) n += 2 * (pipe64_nz(cls, wlen) * 16 + 15 * 16 + nc / 2) + dctElems;
     return (n + 1) & ~1;
 }
