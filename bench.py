@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the MI355X extraction path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c1|c2|c3|c4|c5] [--precision f32|f64]
+    python bench.py --gpus N --steps K --warmup W [--workload c1|c2|c3|c4|c5] [--precision auto|f32|f64]
 
 A step is one pass of the device-resident hot path (static-feature kernel, then deltas / z-norm
 when the option set has them) over one batch of synthetic audio that already sits in HBM.
+The line is in the precision that meets the stated tolerance on the workload's PCM format (single
+for the 16-bit workloads c2 / c3, double for the 24-bit ones); the same workload timed in the
+other precision is the side record "f64" / "f32" of the same line.
 
 Workloads (the five benchmark configurations):
   c2 (default)  16 kHz mono 25 ms / 10 ms, 40-bin log-mel, 10 000 utterances of 10 s per GPU
@@ -171,33 +174,61 @@ def cpu_baseline(kw, buf, offs, lengths, channels, bps):
                       % (n, reps, reps * int(csum[n - 1]), dt, n1, dt1)}
 
 
+VALU_PEAK = {"f32": 157.3e12, "f64": 78.6e12}  # vector FLOP/s of one MI355X (no matrix cores)
+
+
 def profile_numbers(workload, n_utts, precision):
     """HBM traffic and unit-busy fractions of the static-feature kernel from the committed
-    rocprofv3 counter passes of this workload (measured in a profiling run of this same command,
-    not in this run: counters cannot be read from inside the timed region)."""
+    rocprofv3 counter passes of this workload and precision (measured in a profiling run of this
+    same command, not in this run: counters cannot be read from inside the timed region)."""
     res = {"traffic": None}
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
-    if os.path.exists(tpath):
+    for tname in ("r03_%s_%s_traffic.json" % (workload, precision), "traffic_%s.json" % workload):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tpath):
+            continue
         try:
             with open(tpath) as f:
                 tj = json.load(f)
             if tj.get("utts") == n_utts and tj.get("precision") == precision:
                 res["traffic"] = tj.get("hbm_bytes_per_launch")
-                res["traffic_source"] = "profiles/traffic_%s.json (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command)" % workload
+                res["traffic_source"] = "profiles/%s (rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command)" % tname
+                break
         except Exception:
             pass
-    cpath = os.path.join(ROOT, "profiles", "r02_%s_counters.json" % workload)
-    if os.path.exists(cpath) and precision == "f32":
+    for cname in ("r03_%s_%s_counters.json" % (workload, precision),) + (("r02_%s_counters.json" % workload,) if precision == "f32" else ()):
+        cpath = os.path.join(ROOT, "profiles", cname)
+        if not os.path.exists(cpath):
+            continue
         try:
             with open(cpath) as f:
                 cj = json.load(f)
-            for k in ("valu_frac", "lds_frac"):
+            for k in ("valu_frac", "lds_frac", "mfma_frac"):
                 if k in cj:
                     res[k] = cj[k]
-            res["counters_source"] = "profiles/r02_%s_counters.json" % workload
+            pf = cj.get("per_frame", {})
+            if "SQ_INSTS_VALU" in pf:
+                res["valu_instr_per_frame"] = pf["SQ_INSTS_VALU"]
+            if "SQ_LDS_IDX_ACTIVE" in pf:
+                # an LDS-active cycle moves at most 128 bytes per CU
+                res["lds_cycles_per_frame"] = pf["SQ_LDS_IDX_ACTIVE"]
+                res["lds_bytes_per_frame_at_peak"] = 128.0 * pf["SQ_LDS_IDX_ACTIVE"]
+            res["counters_source"] = "profiles/" + cname
+            break
         except Exception:
             pass
     return res
+
+
+def flops_per_frame(kw):
+    """Algorithmic FLOP of one frame (all vecNum rows): FFT 2.5 F log2(F/2), split + power + mel +
+    centroid 4 F, pre-emphasis + window + energy + ZCR 6 W, cepstra 2 M P, logs 20 P."""
+    W, P = kw["wlen"], kw["bankNum"]
+    F = 2
+    while F < W:
+        F *= 2
+    M = 0 if kw.get("fbankFlag", 1) else kw.get("MFCCNum", 0) + kw.get("MFCC0thFlag", 0)
+    per_row = 2.5 * F * (np.log2(F) - 1) + 4 * F + 6 * W + 2 * M * P + 20 * P
+    return float(per_row * kw.get("vecNum", 1))
 
 
 def main():
@@ -207,16 +238,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--utts", type=int, default=0, help="utterances per GPU (0 = workload default)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--precision", default="auto", choices=["auto", "f32", "f64"],
+                    help="auto: the precision that meets the stated tolerance on the workload's PCM format "
+                         "(mfcc_amd.presets.BENCH_PRECISION); the other one is reported beside it")
     ap.add_argument("--tune", default="", help="plan-heuristic overrides for measurements, key=value,... (MFCCDebugTuning)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
+    ap.add_argument("--no-other", action="store_true", help="skip the leg in the other precision")
     args = ap.parse_args()
 
     import torch
     import mfcc_amd as ma
-    from mfcc_amd.presets import CONFIGS
+    from mfcc_amd.presets import CONFIGS, BENCH_PRECISION
 
+    if args.precision == "auto":
+        args.precision = BENCH_PRECISION[args.workload]
     if args.tune:
         ma.tuning(**{k: int(v) for k, v in (item.split("=") for item in args.tune.split(",") if item)})
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -245,49 +281,26 @@ def main():
     if args.utts:
         n_utts = args.utts
     kw = CONFIGS[key]
-    prec = ma.PREC_F64 if args.precision == "f64" else ma.PREC_F32
-    cfg = ma.make_config(precision=prec, **kw)
     sr, bpi = kw["sampleRate"], channels * bps
-    el = 8 if args.precision == "f64" else 4
-    step, vsize = ma.step(cfg), ma.step(cfg) // kw.get("regreOrder", 1)
     zm, zn = kw.get("zeroMeanSigFlag", 0), kw.get("znormFlag", 0)
-    # algorithmic bytes per frame: the PCM of one frame shift read once (twice with zero-mean), every
-    # output element written once (and read + rewritten by the z-norm); the static-feature kernel
-    # alone reads the PCM and writes its own vSize columns
-    pass_bytes = bpi * kw["inc"] * (1 + zm) + step * el * (1 + 2 * zn)
-    kernel_bytes = bpi * kw["inc"] + vsize * el
-
-    ctx = ma.Context(cfg, local_rank)
     sharded = args.workload == "c5"
     device = "cuda:%d" % local_rank
+    from mfcc_amd import sharding
+
+    # the batch (the same bytes for both precisions)
+    cfg0 = ma.make_config(precision=ma.PREC_F32, **kw)
     if sharded:
         total = C5_SAMPLES if not args.utts else args.utts * sr * 60  # --utts N: an N-minute recording instead
         T = ma.num_frames(total, kw["wlen"], kw["inc"])
         fb, fe = T * rank // world, T * (rank + 1) // world
-        g = ma.shard_geometry(cfg, total, fb, fe)
+        g = ma.shard_geometry(cfg0, total, fb, fe)
         buf = np.zeros(g["sample_count"] * bpi, dtype=np.uint8)
         synth_range(ma, buf.ctypes.data, channels, bps, g["sample_begin"], g["sample_count"], 0x5EED0000 + 5000, sr)
-        plan = ma.Plan(ctx, channels, bps, shard=(total, fb, fe, None))
-        frames = fe - fb
-        total_frames = T
         offs, lengths = np.zeros(1, dtype=np.int64), np.array([g["sample_count"]], dtype=np.int64)
     else:
         lengths = utterance_lengths(args.workload, kw, n_utts, rank)
         buf, offs = synth_batch(ma, lengths, channels, bps, sr, 0x5EED0000 + 1000 * 2 + 100000 * rank)
-        plan = ma.Plan(ctx, channels, bps, offs, lengths)
-        frames = plan.total_rows
-        total_frames = frames * world
     pcm_dev = torch.from_numpy(buf).to(device)
-    out = plan.alloc_output()
-    plan.enable_timing(True)
-    from mfcc_amd import sharding
-
-    def one_pass():
-        plan.extract(pcm_dev, out)
-        if sharded and zn:
-            sums = plan.shard_column_sums(out)
-            sums = sharding.combine_sums(sums, dist)  # all_gather over RCCL + rank-ordered sum
-            plan.shard_normalize(out, sums)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -295,35 +308,86 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if rank == 0:
-        print("bench: %s, %d frames on this rank, inputs resident" % (args.workload, frames), file=sys.stderr, flush=True)
-    for _ in range(args.warmup):
-        one_pass()
-    sync_all()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_pass()
-        kernel_ms.append(plan.last_kernel_ms())  # waits for the kernel's stop event
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(precision, steps, warmup):
+        """Times `steps` passes in one precision; returns (record for the JSON line, one_pass, out)."""
+        prec = ma.PREC_F64 if precision == "f64" else ma.PREC_F32
+        cfg = ma.make_config(precision=prec, **kw)
+        el = 8 if precision == "f64" else 4
+        step, vsize = ma.step(cfg), ma.step(cfg) // kw.get("regreOrder", 1)
+        # algorithmic bytes per frame: the PCM of one frame shift read once (twice with zero-mean), every
+        # output element written once (and read + rewritten by the z-norm); the static-feature kernel
+        # alone reads the PCM and writes its own vSize columns
+        pass_bytes = bpi * kw["inc"] * (1 + zm) + step * el * (1 + 2 * zn)
+        kernel_bytes = bpi * kw["inc"] + vsize * el
+        ctx = ma.Context(cfg, local_rank)
+        if sharded:
+            plan = ma.Plan(ctx, channels, bps, shard=(total, fb, fe, None))
+            frames, total_frames = fe - fb, T
+        else:
+            plan = ma.Plan(ctx, channels, bps, offs, lengths)
+            frames = plan.total_rows
+            total_frames = frames * world
+        out = plan.alloc_output()
+        plan.enable_timing(True)
 
-    if rank == 0:
-        value = total_frames * args.steps / elapsed
+        def one_pass():
+            plan.extract(pcm_dev, out)
+            if sharded and zn:
+                sums = plan.shard_column_sums(out)
+                sums = sharding.combine_sums(sums, dist)  # all_gather over RCCL + rank-ordered sum
+                plan.shard_normalize(out, sums)
+
+        if rank == 0:
+            print("bench: %s %s, %d frames on this rank, inputs resident" % (args.workload, precision, frames), file=sys.stderr, flush=True)
+        for _ in range(warmup):
+            one_pass()
+        sync_all()
+        kernel_ms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_pass()
+            kernel_ms.append(plan.last_kernel_ms())  # waits for the kernel's stop event
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        value = total_frames * steps / elapsed
         kavg = float(np.mean(kernel_ms)) * 1e-3
         achieved = frames * kernel_bytes / kavg
-        prof = profile_numbers(args.workload, n_utts, args.precision)
-        roofline = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+        prof = profile_numbers(args.workload, n_utts, precision)
+        flops = flops_per_frame(kw)
+        alu_frac = frames * flops / kavg / VALU_PEAK[precision]
+        # which unit limits the kernel: the memory system if its fraction is the largest, else the
+        # busiest on-chip units (vector ALUs / LDS busy fractions from the committed counter passes)
+        units = {"hbm": achieved / HBM_PEAK}
+        if "valu_frac" in prof:
+            units["valu"] = prof["valu_frac"]
+        if "lds_frac" in prof:
+            units["lds"] = prof["lds_frac"]
+        top = max(units.values())
+        bound = "+".join(k for k in ("hbm", "lds", "valu") if k in units and units[k] >= 0.8 * top)
+        if len(units) == 1:
+            bound = "hbm (nominal: no counter pass of this workload and precision is committed)"
+        roofline = {"bound": bound, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                    "kernel": "static-feature kernel (k_lean256: c2, c3; k_wide1024: c1, c4, c5; k_front in f64)", "kernel_ms": kavg * 1e3,
+                    "kernel": "static-feature kernel (f32: k_lean256 c2, c3; k_wide1024 c1, c4, c5; f64: k_pipe64)",
+                    "kernel_ms": kavg * 1e3,
                     "algorithmic_bytes_per_frame": kernel_bytes,
+                    "algorithmic_flop_per_frame": flops,
+                    "alu_frac": alu_frac, "alu_peak_tflops": VALU_PEAK[precision] / 1e12,
                     "whole_pass": {"algorithmic_bytes_per_frame": pass_bytes,
-                                   "frac": total_frames * pass_bytes * args.steps / elapsed / (HBM_PEAK * world)}}
+                                   "frac": total_frames * pass_bytes * steps / elapsed / (HBM_PEAK * world)}}
         roofline.update(prof)
+        rec = {"value": value, "ms_per_step": elapsed / steps * 1e3, "frames": int(frames), "roofline": roofline}
+        return rec, one_pass, out, plan, ctx
+
+    rec, one_pass, out, plan, ctx = measure(args.precision, args.steps, args.warmup)
+    frames = rec["frames"]
+    line = None
+    if rank == 0:
+        value = rec["value"]
         line = {
             "metric": "frames/sec",
             "value": value,
@@ -331,7 +395,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
@@ -343,25 +407,46 @@ def main():
                        "parallelism": ("frame ranges sharded by rank, halo frames recomputed, z-norm column sums exchanged "
                                        "(all_gather + rank-ordered sum)") if sharded
                        else "utterances sharded by rank, no collective"},
-            "roofline": roofline,
+            "roofline": rec["roofline"],
         }
-        if not args.no_host and world == 1:
-            # Same pass with the batch starting and ending in pinned host memory (what a caller
-            # of the host-buffer entry points sees); reported beside `value`, never as it.
-            pcm_host = torch.from_numpy(buf).pin_memory()
-            out_host = torch.empty(out.shape, dtype=out.dtype).pin_memory()
-            reps = 3
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                pcm_dev.copy_(pcm_host, non_blocking=True)
-                one_pass()
-                out_host.copy_(out, non_blocking=True)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / reps
-            line["host_buffers"] = {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
-                                    "note": "pinned host PCM -> HBM -> kernels -> pinned host features"}
-            del pcm_host, out_host
+    if not args.no_host and world == 1:
+        # Same pass with the batch starting and ending in pinned host memory (what a caller
+        # of the host-buffer entry points sees); reported beside `value`, never as it.
+        pcm_host = torch.from_numpy(buf).pin_memory()
+        out_host = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+        reps = 3
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            pcm_dev.copy_(pcm_host, non_blocking=True)
+            one_pass()
+            out_host.copy_(out, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        line["host_buffers"] = {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                                "note": "pinned host PCM -> HBM -> kernels -> pinned host features"}
+        del pcm_host, out_host
+    del out, one_pass
+    plan.close()
+    ctx.close()
+    if not args.no_other:
+        # the same workload, steps and timing in the other precision, beside the headline
+        other = "f64" if args.precision == "f32" else "f32"
+        rec2, _, out2, plan2, ctx2 = measure(other, args.steps, args.warmup)
+        del out2
+        plan2.close()
+        ctx2.close()
+        if rank == 0:
+            r2 = rec2["roofline"]
+            line[other] = {"value": rec2["value"], "ms_per_step": rec2["ms_per_step"], "kernel_ms": r2["kernel_ms"],
+                           "frac": r2["frac"], "alu_frac": r2["alu_frac"], "bound": r2["bound"],
+                           "algorithmic_bytes_per_frame": r2["algorithmic_bytes_per_frame"],
+                           "whole_pass_frac": r2["whole_pass"]["frac"],
+                           "note": ("double precision: the library default and the reference's arithmetic (agreement 1e-11)"
+                                    if other == "f64" else
+                                    "single precision: misses the 1e-4 log-mel tolerance on 24-bit input in channels 60 dB "
+                                    "or more below the frame's strongest one")}
+    if rank == 0:
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(kw, buf, offs, lengths, channels, bps)
         print(json.dumps(line), flush=True)

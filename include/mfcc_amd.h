@@ -253,9 +253,15 @@ int MFCCExtractRecording(const MFCCConfig *cfg, const void *pcm, int channels, i
  * hipFree.  The per-chunk partial sums go to a 4 MiB device array inside the library (one copy
  * per GPU, held until the process ends): ceil(rows / 256) * 2 * step * 8 bytes must fit, larger
  * matrices are refused with MFCC_E_ARG.  All calls on one GPU share that array: calls that
- * overlap there (two streams or threads) race; calls on one stream are ordered. */
+ * overlap there (two streams or threads) race; calls on one stream are ordered.  The stream must
+ * belong to the current device (MFCC_E_ARG otherwise).
+ * Under stream capture: call MFCCColumnSumsNoAllocWarmup() once per device before the capture
+ * begins.  It does eagerly what the first call on a device would otherwise do inside the capture
+ * (the look-up of the array's device address and the loading of the kernels) and synchronises;
+ * afterwards a call only enqueues kernels on the stream. */
 int MFCCColumnSumsNoAlloc(int precision, const void *dataDev, int64_t rows, int step, double *sumsDev,
                           void *stream);
+int MFCCColumnSumsNoAllocWarmup(void);
 
 /* ------------------------------------------------------------------------------------------
  * The reference's lower-level API (mfcc.h:29-74), batched on the device: numFrames vectors back

@@ -1662,7 +1662,7 @@ extern "C" int MFCCShardColumnSums(MFCCContext *c, MFCCPlan *p, const void *outD
     int rc = run_colstats(c, p, const_cast<void *>(outDev), stream);
     if (rc) return rc;
     StatArgs<float> fa = stat_args<float>(c, p, nullptr);
-    const int e = launch_shardfinal(fa, p->numChunks, false, sumsDev, stream);
+    const int e = launch_shardfinal(fa, p->numChunks, 0, sumsDev, stream);
     if (e) return set_error("shard statistics kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
     return MFCC_OK;
 }
@@ -1724,7 +1724,8 @@ extern "C" int MFCCWave2FBankDevice(MFCCContext *c, const void *framesDev, int n
     DEVICE_SCOPE(c->device);
     const int rc = launch_wave2fbank_batch(c->cfg.precision == MFCC_PREC_F64, framesDev, fbankDev, teDev, nullptr,
                                            nullptr, numFrames, c->cfg.wlen, c->tab.fftN, c->tab.klo, c->tab.khi,
-                                           c->cfg.bankNum, c->dLoChan, c->dLoWt, 1, 1, stream);
+                                           c->cfg.bankNum, c->dLoChan, c->dLoWt, c->cfg.usePower ? 1 : 0,
+                                           c->cfg.takeLogs ? 1 : 0, stream);
     if (rc) return set_error("Wave2FBank kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;
 }

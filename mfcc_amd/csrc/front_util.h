@@ -4,12 +4,30 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "fft_regs.h"
 #include "mfcc_dev.h"
 
 namespace mfcc {
+
+// Raises a kernel's dynamic-LDS limit to the CU's 160 KB, once per device and kernel (the launchers
+// run concurrently from the device threads of MFCCWapperList / MFCCExtractRecording, hence the
+// atomics; a device index beyond the table sets the attribute on every call).  `done`: one
+// function-local static table per kernel instantiation.
+constexpr int kAttrDevices = 64;
+inline hipError_t lds_limit_once(const void *kernel, std::atomic<bool> (&done)[kAttrDevices])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool known = dev >= 0 && dev < kAttrDevices;
+    if (known && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && known) done[dev].store(true, std::memory_order_release);
+    return e;
+}
 
 // PPLOG: log2 of the complex points a lane keeps in registers (4 -> radix-16 stages, 3 -> radix-8,
 // 2 -> radix-4).  Fewer points per lane means more lanes per frame, fewer frames in flight per

@@ -480,16 +480,9 @@ bool lean256_applies(int log2nc, int mode, int inc, int wlen, int melSteps)
 template <int NZ, int WAVES, int MSG>
 static int launch_lean_t(const FrontArgs<float> &a, int numBlocks, size_t lds, hipStream_t st)
 {
-    static bool attrSet[16] = {};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static std::atomic<bool> attrSet[kAttrDevices];
+    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_lean256<NZ, WAVES, MSG>), attrSet);
     if (e != hipSuccess) return (int)e;
-    if (dev >= 16 || !attrSet[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lean256<NZ, WAVES, MSG>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        if (dev < 16) attrSet[dev] = true;
-    }
     hipLaunchKernelGGL((k_lean256<NZ, WAVES, MSG>), dim3(numBlocks), dim3(WAVES * 64), lds, st, a);
     return (int)hipGetLastError();
 }

@@ -182,7 +182,7 @@ int front_occupancy(int precision, int log2nc, int pplog, bool tabLds, int mode,
 int launch_regress(int precision, const void *args, int numBlocks, void *stream);
 int launch_colstats(int precision, const void *args, int numChunks, void *stream);
 int launch_colfinal(const StatArgs<float> &a, int numUtts, int blockRows, void *stream); // blockRows > 0: partial sums per block of that many rows
-int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, double *sumsOut, void *stream);
+int launch_shardfinal(const StatArgs<float> &a, int numChunks, int blockRows, double *sumsOut, void *stream);
 int launch_delta(int precision, const void *args, int orders, size_t ldsBytes, void *stream); // -2: no such variant
 int launch_utt_finish(int precision, const void *args, int orders, int numUtts, size_t ldsBytes, void *stream);
 int launch_energy_norm(int precision, void *data, const UttDesc *utts, int numUtts, int step, int col, double silFloor,

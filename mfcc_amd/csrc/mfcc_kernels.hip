@@ -1201,14 +1201,8 @@ __global__ void k_uttmeans(UttDesc *utts, int numUtts, const unsigned long long 
 template <typename T, int L, int PL, bool TLDS, int MODE>
 static int launch_front_t(const FrontArgs<T> &a, int numBlocks, size_t lds, hipStream_t st)
 {
-    static bool attrSet[16] = {};
-    int dev = 0;
-    MFCC_HIP_OK(hipGetDevice(&dev));
-    if (dev < 16 && !attrSet[dev]) {
-        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS, MODE>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attrSet[dev] = true;
-    }
+    static std::atomic<bool> attrSet[kAttrDevices];
+    MFCC_HIP_OK(lds_limit_once(reinterpret_cast<const void *>(&k_front<T, L, PL, TLDS, MODE>), attrSet));
     hipLaunchKernelGGL((k_front<T, L, PL, TLDS, MODE>), dim3(numBlocks), dim3(kBlock), lds, st, a);
     return (int)hipGetLastError();
 }
@@ -1355,11 +1349,13 @@ int launch_colfinal(const StatArgs<float> &a, int numUtts, int blockRows, void *
     return (int)hipGetLastError();
 }
 
-int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, double *sumsOut, void *stream)
+// blockRows: 0 = the partials are per statistics chunk (kStatRows rows), else per regression block of
+// that many rows (the plan's regRows)
+int launch_shardfinal(const StatArgs<float> &a, int numChunks, int blockRows, double *sumsOut, void *stream)
 {
     (void)numChunks;
     hipLaunchKernelGGL(k_shardfinal, dim3(1, (2 * a.step + kFinalCols - 1) / kFinalCols), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       a.utts, a.partial, sumsOut, a.step, byBlock ? kRegRows : 0);
+                       a.utts, a.partial, sumsOut, a.step, blockRows);
     return (int)hipGetLastError();
 }
 
@@ -1367,14 +1363,8 @@ int launch_shardfinal(const StatArgs<float> &a, int numChunks, bool byBlock, dou
 template <typename T, int ORD>
 static int launch_delta_o(const DeltaArgs<T> &a, size_t lds, hipStream_t st)
 {
-    static bool attrSet[16] = {};
-    int dev = 0;
-    MFCC_HIP_OK(hipGetDevice(&dev));
-    if (dev < 16 && !attrSet[dev]) {
-        MFCC_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta<T, ORD>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attrSet[dev] = true;
-    }
+    static std::atomic<bool> attrSet[kAttrDevices];
+    MFCC_HIP_OK(lds_limit_once(reinterpret_cast<const void *>(&k_delta<T, ORD>), attrSet));
     hipLaunchKernelGGL((k_delta<T, ORD>), dim3(a.numBlocks), dim3(kBlock), lds, st, a);
     return (int)hipGetLastError();
 }

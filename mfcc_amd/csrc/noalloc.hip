@@ -6,6 +6,11 @@
 //
 // Every device the library runs on holds its own copy of the array until the process ends.  All
 // calls on one device share it: calls that overlap on one device (two streams, two threads) race.
+//
+// Under stream capture: the first call on a device looks the array's address up
+// (hipGetSymbolAddress) and may make the runtime load this library's kernels, neither of which
+// belongs inside a capture.  MFCCColumnSumsNoAllocWarmup does both eagerly, once per device, before
+// the capture begins; after it, a call only enqueues kernels (and one memset when rows = 0).
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -54,11 +59,43 @@ int scratch_of_current_device(unsigned char **out)
     return MFCC_OK;
 }
 
+// The device the work will run on: the stream's, which must be the current one (the scratch
+// address and the kernels' module belong to the current device).
+int check_stream_device(hipStream_t st)
+{
+    if (!st) return MFCC_OK; // the null stream is the current device's
+    int cur = -1;
+    hipDevice_t sdev = -1;
+    if (hipGetDevice(&cur) != hipSuccess || hipStreamGetDevice(st, &sdev) != hipSuccess) return MFCC_OK; // (cannot tell: let the launch report it)
+    if ((int)sdev != cur)
+        return set_error("MFCCColumnSumsNoAlloc: the stream belongs to device %d, the current device is %d", (int)sdev, cur), MFCC_E_ARG;
+    return MFCC_OK;
+}
+
 } // namespace
 
 } // namespace mfcc
 
 using namespace mfcc;
+
+extern "C" int MFCCColumnSumsNoAllocWarmup(void)
+{
+    unsigned char *base = nullptr;
+    const int rc = scratch_of_current_device(&base);
+    if (rc) return rc;
+    // one run of each kernel on a one-row matrix inside the scratch itself: loads the code objects
+    float *probe = reinterpret_cast<float *>(base + kHeadBytes + kPartialBytes - 256);
+    double *sums = reinterpret_cast<double *>(base + kHeadBytes + kPartialBytes - 128);
+    hipError_t e = hipMemsetAsync(probe, 0, 256, nullptr);
+    if (e != hipSuccess) return set_error("hipMemsetAsync failed (HIP error %d)", (int)e), MFCC_E_DEVICE;
+    for (int prec : {MFCC_PREC_F32, MFCC_PREC_F64}) {
+        const int r = MFCCColumnSumsNoAlloc(prec, probe, 1, 1, sums, nullptr);
+        if (r) return r;
+    }
+    e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) return set_error("warm-up kernels failed (HIP error %d)", (int)e), MFCC_E_DEVICE;
+    return MFCC_OK;
+}
 
 extern "C" int MFCCColumnSumsNoAlloc(int precision, const void *dataDev, int64_t rows, int step, double *sumsDev,
                                      void *stream)
@@ -71,10 +108,12 @@ extern "C" int MFCCColumnSumsNoAlloc(int precision, const void *dataDev, int64_t
                          "(use MFCCShardColumnSums with a plan for larger matrices)",
                          (long long)rows, step, (unsigned long long)chunks * 2 * (unsigned long long)step * sizeof(double), kPartialBytes),
                MFCC_E_ARG;
-    unsigned char *base = nullptr;
-    const int rc = scratch_of_current_device(&base);
-    if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned char *base = nullptr;
+    int rc = check_stream_device(st);
+    if (rc) return rc;
+    rc = scratch_of_current_device(&base);
+    if (rc) return rc;
     hipError_t e;
     if (rows == 0) {
         e = hipMemsetAsync(sumsDev, 0, (size_t)(2 * step + 1) * sizeof(double), st);
@@ -110,7 +149,7 @@ extern "C" int MFCCColumnSumsNoAlloc(int precision, const void *dataDev, int64_t
     fa.utts = utt;
     fa.step = step;
     fa.partial = partial;
-    lrc = launch_shardfinal(fa, (int)chunks, false, sumsDev, stream);
+    lrc = launch_shardfinal(fa, (int)chunks, 0, sumsDev, stream);
     if (lrc) return set_error("shard statistics kernel launch failed (HIP error %d)", lrc), MFCC_E_DEVICE;
     return MFCC_OK;
 }

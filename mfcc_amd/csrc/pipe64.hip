@@ -764,16 +764,9 @@ int pipe64_tab_elems(int cls, int wlen, int dctElems, int melSteps)
 template <int LOG2NC, int CH, int BPS, int NZ>
 static int launch_pipe_t(const FrontArgs<double> &a, int numBlocks, size_t lds, hipStream_t st)
 {
-    static std::atomic<bool> attrSet[64];
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static std::atomic<bool> attrSet[kAttrDevices];
+    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_pipe64<LOG2NC, CH, BPS, NZ>), attrSet);
     if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64 || !attrSet[dev].load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pipe64<LOG2NC, CH, BPS, NZ>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        if (dev >= 0 && dev < 64) attrSet[dev].store(true, std::memory_order_release);
-    }
     hipLaunchKernelGGL((k_pipe64<LOG2NC, CH, BPS, NZ>), dim3(numBlocks), dim3(kPipeWaves * 64), lds, st, a);
     return (int)hipGetLastError();
 }

@@ -756,16 +756,9 @@ bool wide1024_applies(int log2nc, int channels, int bps, int wlen)
 template <int NZ, bool ZC>
 static int launch_wide_t(const FrontArgs<float> &a, int numBlocks, size_t lds, hipStream_t st)
 {
-    static bool attrSet[16] = {};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
+    static std::atomic<bool> attrSet[kAttrDevices];
+    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_wide1024<NZ, ZC>), attrSet);
     if (e != hipSuccess) return (int)e;
-    if (dev >= 16 || !attrSet[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide1024<NZ, ZC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        if (dev < 16) attrSet[dev] = true;
-    }
     hipLaunchKernelGGL((k_wide1024<NZ, ZC>), dim3(numBlocks), dim3(kWideWaves * 64), lds, st, a);
     return (int)hipGetLastError();
 }

@@ -82,8 +82,10 @@ def split_file_list(ini_path, rank, world_size, out_dir, file_list=None):
     """This rank's share of a run: reads the `src<TAB>dst` list the ini names (main.c:173-177: up
     to the first blank line), gives every rank the files shard_files assigns it by size on disk
     (longest first; a missing file counts as empty and is reported by the rank that gets it), and
-    writes `rank<r>.list` and `rank<r>.ini` (the original ini with its fileList line replaced) into
-    out_dir.  file_list: the list path, if the caller already parsed the ini.
+    writes `rank<r>.list` and `rank<r>.ini` (the original ini with its fileList line replaced and
+    `[IO] numDevices = 1`: a rank is one process on one GPU, the caller's current device, so it must
+    not start a device thread per visible GPU as a lone process does) into out_dir.
+    file_list: the list path, if the caller already parsed the ini.
     Returns (path of the per-rank ini, indices of this rank's lines)."""
     text = open(ini_path, encoding="utf-8-sig").read()
     key = re.compile(r"^(\s*fileList\s*[=:]\s*)([^;#\n]*?)(\s*(?:[;#].*)?)$", re.M)
@@ -111,16 +113,22 @@ def split_file_list(ini_path, rank, world_size, out_dir, file_list=None):
     with open(lst, "w") as f:
         f.writelines(lines[i] for i in mine)
     ini = os.path.join(out_dir, "rank%d.ini" % rank)
+    body = (key.sub(lambda mm: mm.group(1) + lst + mm.group(3), text, count=1) if m
+            else text + "\n[IO]\nfileList = %s\n" % lst)
+    # drop any numDevices line of the original and pin the rank to one device thread
+    body = re.sub(r"^\s*numDevices\s*[=:].*\n?", "", body, flags=re.M)
+    if not body.endswith("\n"):
+        body += "\n"
+    body += "[IO]\nnumDevices = 1\n"
     with open(ini, "w") as f:
-        f.write(key.sub(lambda mm: mm.group(1) + lst + mm.group(3), text, count=1) if m
-                else text + "\n[IO]\nfileList = %s\n" % lst)
+        f.write(body)
     return ini, mine
 
 
 def wapper_list_sharded(ma, ini_path, out_dir, dist=None):
     """The whole run (MFCCWapperList = main.c:98-300) over the GPUs of a node: every rank takes its
-    share of the file list (split_file_list) and runs it on its own GPU; nothing is exchanged on
-    the data path.  Returns (failed files of this rank, failed files of all ranks)."""
+    share of the file list (split_file_list) and runs it on its own GPU (the process's current
+    device; the rank's ini says numDevices = 1); nothing is exchanged on the data path.  Returns (failed files of this rank, failed files of all ranks)."""
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     ini, _ = split_file_list(ini_path, rank, world, out_dir)

@@ -196,12 +196,14 @@ def fft(x, invert=0):
     return s
 
 
-def wave2fbank(frame, sample_rate, num_chans, lopass, hipass):
-    """Returns (fbank, te, te2, packed spectrum)."""
+def wave2fbank(frame, sample_rate, num_chans, lopass, hipass, use_power=1, take_logs=1):
+    """Returns (fbank, te, te2, packed spectrum).  use_power / take_logs: FBankInfo's fields
+    (mfcc.c:154-157,171-176)."""
     fb = OrcFBank()
     s = np.ascontiguousarray(frame, dtype=np.float64)
     lib().orc_fbank_init(C.byref(fb), s.size, 1e7 / float(sample_rate), num_chans, float(lopass),
                          float(hipass))
+    fb.usePower, fb.takeLogs = int(use_power), int(take_logs)
     fbank = np.zeros(num_chans)
     x = np.zeros(fb.fftN)
     te = C.c_double()

@@ -2,11 +2,14 @@
 libmfcc_amd.so, against the CPU oracle on the same seeded inputs, against the committed golden
 fixtures, and -- at the benchmark's full sizes -- through size-independent properties.
 
-Tolerances (single precision kernels, the shipped default): log-mel and log-energy 1e-4 absolute,
-cepstra / C0 1e-5 relative to the largest cepstral magnitude, ZCR exact, brightness / sub-band
-fractions 1e-5 absolute; deltas inherit the tolerance of their static column; z-normalised
-columns 2e-3 absolute (errors are divided by the column's standard deviation).  Double precision
-kernels must agree to 1e-9.  Frame counts, row layout and indexing must be exact."""
+Tolerances (single precision kernels; util.kind_tolerance): log-mel 1e-4 absolute, cepstra 4e-6
+and C0 1e-6 relative to the largest such magnitude of the matrix (the stated bar is 1e-5; an
+absolute floor covers matrices whose cepstra are all small), ZCR exact, log energy 2e-5,
+brightness / sub-band fractions 6e-7 absolute; deltas inherit the tolerance of their static
+column; z-normalised columns: the kind's tolerance divided by the column's standard deviation
+(util.assert_znorm_close).  Double precision kernels (the library default) must agree to 1e-9.
+Frame counts, row layout and indexing must be exact.  The largest error each kind reached is
+printed at the end of the run."""
 import glob
 import json
 import os
@@ -48,15 +51,24 @@ def _layout(kw):
     return (1 if kw["vecNum"] == 1 else 2), (2 if kw["sampleRate"] == 16000 else 3)
 
 
-def _compare(got, ref, kw, f64):
-    """Static block by kind; delta blocks with the same per-kind tolerance; everything loosened
-    to 2e-3 when the matrix was z-normalised."""
+def _compare(got, ref, kw, f64, src=None):
+    """Static block by kind; delta blocks with the same per-kind tolerance.  z-normalised matrices:
+    per column kind with the kind's tolerance divided by the column's standard deviation
+    (util.assert_znorm_close) when src = (oracle, pcm, channels, bytes per sample) lets the
+    un-normalised reference be formed; without it, 3e-4 (1e-8 in double) for the whole matrix."""
     assert got.shape == ref.shape
     if kw.get("znormFlag", 0):
+        if src is not None:
+            orc, pcm, ch, bps = src
+            raw = orc.extract_pcm_bytes(orc.make_config(**dict(kw, znormFlag=0)), np.frombuffer(bytes(pcm), dtype=np.uint8), ch, bps)
+            util.assert_znorm_close(got, ref, raw, kw, f64)
+            return
         assert np.array_equal(np.isnan(got), np.isnan(ref))
         fin = np.isfinite(ref)
-        tol = 1e-8 if f64 else 2e-3
-        assert np.max(np.abs(np.where(fin, got - ref, 0.0)), initial=0.0) < tol
+        tol = 1e-8 if f64 else 3e-4
+        err = float(np.max(np.abs(np.where(fin, got - ref, 0.0)), initial=0.0))
+        util._note("znorm %s(z units, whole matrix)" % ("f64 " if f64 else ""), err, tol)
+        assert err < tol
         return
     vs = len(column_kinds(kw)) * kw.get("vecNum", 1)
     for o in range(kw.get("regreOrder", 1)):
@@ -80,18 +92,18 @@ def test_named_configs_match_oracle(oracle, name, precision, finish, tuning):
     f64 = precision == "f64"
     cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
     got = run_product_batch(ma, cfg, [pcm.tobytes()], ch, bps)[0]
-    _compare(got, ref, kw, f64)
+    _compare(got, ref, kw, f64, src=(oracle, pcm, ch, bps))
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))))
-def test_golden_fixtures(path):
+def test_golden_fixtures(oracle, path):
     z = np.load(path)
     kw = json.loads(str(z["config"]))
     ch, bps = int(z["channels"]), int(z["bytes_per_sample"])
     for f64 in (False, True):
         cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
         got = run_product_batch(ma, cfg, [z["pcm"].tobytes()], ch, bps)[0]
-        _compare(got, z["expected"], kw, f64)
+        _compare(got, z["expected"], kw, f64, src=(oracle, z["pcm"], ch, bps))
 
 
 @pytest.mark.parametrize("wlen", [3, 4, 5, 8, 9, 16, 17, 33, 64, 100, 129, 200, 256, 400, 513, 1024,
@@ -206,10 +218,10 @@ def test_random_configurations(oracle, seed, tuning):
     for f64 in (False, True):
         cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
         gots = run_product_batch(ma, cfg, pcms, ch, bps, pad=int(rng.integers(0, 7)))
-        for got, ref in zip(gots, refs):
+        for got, ref, p in zip(gots, refs, pcms):
             assert got.shape == ref.shape
             if ref.shape[0] >= 5 or not kw["znormFlag"]:  # z-norm over a few rows magnifies last-bit differences (0/0 vs +-1)
-                _compare(got, ref, kw, f64)
+                _compare(got, ref, kw, f64, src=(oracle, p, ch, bps))
 
 
 @pytest.mark.parametrize("finish", ["utterance", "blocks", "too long"])
@@ -228,7 +240,7 @@ def test_ragged_batch_and_edge_lengths(oracle, finish, tuning):
     for n, p, g in zip(lens, pcms, got):
         assert g.shape[0] == oracle.num_frames(n, 400, 160) == ma.num_frames(n, 400, 160)
         if g.shape[0] > 1:
-            _compare(g, oracle.extract_pcm_bytes(ocfg, p, 1, 2), kw, False)
+            _compare(g, oracle.extract_pcm_bytes(ocfg, p, 1, 2), kw, False, src=(oracle, p, 1, 2))
         elif g.shape[0] == 1:  # z-norm of a single frame is 0/0 in both
             assert np.all(np.isnan(g))
 
@@ -469,7 +481,7 @@ def test_frame_sharded_recording_matches_whole(oracle, name, n, ch, bps):
         pieces.append(out[plan.owned_row_begin:plan.owned_row_begin + plan.owned_rows])
     torch.cuda.synchronize()
     got = torch.cat(pieces).double().cpu().numpy()
-    _compare(got, ref, kw, False)
+    _compare(got, ref, kw, False, src=(oracle, pcm, ch, bps))
 
 
 def test_batch_order_and_shift_invariance_at_full_size():
@@ -652,6 +664,17 @@ def test_lower_level_api_pieces(oracle, precision):
         wf, wte, _, _ = oracle.wave2fbank(fr, kw["sampleRate"], kw["bankNum"], kw["lowpassfre"], kw["hipassfre"])
         assert np.max(np.abs(fb[i] - wf)) < (1e-10 if f64 else 1e-4), i
         assert abs(te[i] - wte) <= (1e-12 if f64 else 1e-5) * max(wte, 1.0), i
+    # a context with usePower = 0 (and, in double, takeLogs = 0) gives this piece those options too
+    for up, tl in ((0, 1), (0, 0), (1, 0)):
+        if not tl and not f64:
+            continue  # sums without logs span 1e15: compared in double only
+        ctx2 = ma.Context(ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **dict(kw, usePower=up, takeLogs=tl)), 0)
+        fb2, _ = ctx2.wave2fbank(torch.tensor(frames, dtype=dt, device="cuda"))
+        fb2 = fb2.double().cpu().numpy()
+        for i, fr in enumerate(frames):
+            wf, _, _, _ = oracle.wave2fbank(fr, kw["sampleRate"], kw["bankNum"], kw["lowpassfre"], kw["hipassfre"], up, tl)
+            assert np.max(np.abs(fb2[i] - wf)) < (1e-10 * max(1.0, float(np.max(np.abs(wf)))) if f64 else 1e-4), (up, tl, i)
+        ctx2.close()
     fbank = rng.standard_normal((40, kw["bankNum"])) * 5 + 10
     m, c0 = ctx.fbank2mfcc(torch.tensor(fbank, dtype=dt, device="cuda"))
     m, c0 = m.double().cpu().numpy(), c0.double().cpu().numpy()
@@ -831,7 +854,7 @@ def test_options_the_reference_leaves_off_in_the_extraction_path(oracle, name, o
     got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], ch, bps)
     for g, p in zip(got, pcms):
         ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), p, ch, bps)
-        _compare(g, ref, kw, f64)
+        _compare(g, ref, kw, f64, src=(oracle, p, ch, bps))
 
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
@@ -884,7 +907,7 @@ def test_whole_utterance_finish_variants(oracle, name, frames, force_sweeps, tun
     assert got[0].shape[0] == frames and got[2].shape[0] == 0
     for p, g in zip(pcms, got):
         if g.shape[0] >= 5:
-            _compare(g, oracle.extract_pcm_bytes(ocfg, p, ch, bps), kw, False)
+            _compare(g, oracle.extract_pcm_bytes(ocfg, p, ch, bps), kw, False, src=(oracle, p, ch, bps))
 
 
 def test_wapper_from_many_threads_with_more_configs_than_cache_slots():
@@ -941,12 +964,14 @@ def _tonal_pcm(n, ch, bps, sr, seed):
 
 @pytest.mark.parametrize("name", ["c2", "c1a"])
 def test_tonal_input_error_envelope(oracle, name):
-    """Where single precision stops meeting the 1e-4 log-mel tolerance.  The rounding noise of a
-    single-precision FFT is relative to the frame's energy, so a channel far below the strongest one
-    of its frame carries a larger relative error.  Measured here on the worst input the format
-    allows; asserted: double precision (the library's default) meets the tolerance everywhere,
-    single precision meets it for every channel within 60 dB (13.8 log units) of the frame's
-    strongest channel, and its error stays below 5e-3 at any level.  The envelope is printed."""
+    """The worst input a PCM format allows for the 1e-4 log-mel tolerance: a near-full-scale tone
+    over a noise floor 90 dB down, so that weak channels sit far below the strongest one of their
+    frame (the rounding noise of a single-precision FFT is relative to the frame's energy).
+    Asserted: the precision bench.py reports for the configuration's class (presets.BENCH_PRECISION:
+    single for 16-bit input, double for 24-bit input) meets 1e-4 on EVERY channel; double (the
+    library's default) agrees to 1e-9.  For 24-bit input the single-precision error is printed by
+    level and bounded by 1e-4 within 60 dB of the frame's strongest channel and by 5e-3 anywhere."""
+    from mfcc_amd.presets import BENCH_PRECISION
     kw = dict(CONFIGS[name], regreOrder=1, energyFlag=0, zeroCrossingFlag=0, brightFlag=0, subBandEFlag=0)
     ch, bps = _layout(kw)
     sr = kw["sampleRate"]
@@ -958,6 +983,11 @@ def test_tonal_input_error_envelope(oracle, name):
     assert ma.make_config(**kw).precision == ma.PREC_F64
     assert np.max(np.abs(got64 - ref)) < 1e-9
     got32 = run_product_batch(ma, ma.make_config(precision=ma.PREC_F32, **kw), [pcm.tobytes()], ch, bps)[0]
+    benched = BENCH_PRECISION["c2" if name == "c2" else "c1"]
+    got_b = got64 if benched == "f64" else got32
+    err_b = float(np.max(np.abs(got_b - ref)))
+    util._note("tonal %s, benched precision %s (all channels)" % (name, benched), err_b, 1e-4)
+    assert err_b <= 1e-4
     err = np.abs(got32 - ref).reshape(-1, V, P)
     lev = ref.reshape(-1, V, P)
     below = np.max(lev, axis=2, keepdims=True) - lev  # log units below the frame's strongest channel
@@ -966,7 +996,9 @@ def test_tonal_input_error_envelope(oracle, name):
     for lo, hi in zip(edges[:-1], edges[1:]):
         m = (below >= lo) & (below < hi)
         if m.any():
-            print("  %5.0f .. %5.0f dB: %7d values, max error %.3g" % (lo * 4.343, min(hi, 40) * 4.343, int(m.sum()), float(err[m].max())))
+            e = float(err[m].max())
+            print("  %5.0f .. %5.0f dB: %7d values, max error %.3g" % (lo * 4.343, min(hi, 40) * 4.343, int(m.sum()), e))
+            util._note("tonal %s f32, %3.0f+ dB below the frame's peak" % (name, lo * 4.343), e, 1e-4 if hi <= 13.8 else 5e-3)
     assert float(err[below < 13.8].max()) <= 1e-4
     assert float(err.max()) <= 5e-3
 
@@ -984,7 +1016,7 @@ def test_recording_over_several_shards_from_one_process(oracle, zero_mean):
         cfg = ma.make_config(precision=prec, **kw)
         got = ma.extract_recording(cfg, pcm, 2, 3, num_shards=3, devices=[0, 0, 0])
         assert got.shape == ref.shape
-        _compare(got.astype(np.float64), ref, kw, f64)
+        _compare(got.astype(np.float64), ref, kw, f64, src=(oracle, pcm, 2, 3))
     kw2 = dict(kw, znormFlag=0)
     cfg = ma.make_config(precision=ma.PREC_F32, **kw2)
     one = ma.extract_recording(cfg, pcm, 2, 3, num_shards=1)

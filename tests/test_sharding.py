@@ -177,7 +177,8 @@ def test_frame_sharded_flow_world2_gloo(oracle, name, n, ch, bps):
 def test_split_file_list_covers_every_line_once(tmp_path):
     """The per-rank lists of a sharded run: every line up to the first blank one lands on exactly
     one rank, balanced by file size, and the per-rank ini differs from the original only in its
-    fileList line (comment suffix kept)."""
+    fileList line (comment suffix kept) and in `[IO] numDevices = 1` at its end, which replaces any
+    numDevices of the original: a rank drives the one GPU of its process, not every visible one."""
     lines = []
     for i in range(11):
         src = tmp_path / ("s%02d.wav" % i)
@@ -187,7 +188,8 @@ def test_split_file_list_covers_every_line_once(tmp_path):
     lst = tmp_path / "all.list"
     lst.write_text("\n".join(lines) + "\n\nignored\tafter the blank line\n")
     ini = tmp_path / "config.ini"
-    ini.write_text("[Frame];\nsampleRate = 16000 ;\nfileList = %s ; the list\nwlen = 400 ;\n" % lst)
+    body = "[Frame];\nsampleRate = 16000 ;\nfileList = %s ; the list\nwlen = 400 ;\n" % lst
+    ini.write_text(body + "[IO]\nnumDevices = 4 ;\n")
     seen, loads = [], []
     for rank in range(3):
         rini, mine = sharding.split_file_list(str(ini), rank, 3, str(tmp_path / "ranks"))
@@ -196,7 +198,9 @@ def test_split_file_list_covers_every_line_once(tmp_path):
         assert got == [lines[i] for i in mine]
         text = open(rini).read()
         assert "fileList = %s ; the list" % (tmp_path / "ranks" / ("rank%d.list" % rank)) in text
-        assert text.replace(str(tmp_path / "ranks" / ("rank%d.list" % rank)), str(lst)) == ini.read_text()
+        assert text.replace(str(tmp_path / "ranks" / ("rank%d.list" % rank)), str(lst)) == body + "[IO]\n[IO]\nnumDevices = 1\n"
+        cfg = ma.config_from_ini(rini) if hasattr(ma, "config_from_ini") else None
+        assert cfg is None or cfg.numDevices == 1
         loads.append(sum(os.path.getsize(lines[i].split("\t")[0]) for i in mine if i != 4))
     assert sorted(seen) == list(range(11))
     assert max(loads) - min(loads) <= 100 + 37 * 100  # within one largest file

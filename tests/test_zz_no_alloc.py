@@ -75,3 +75,33 @@ def test_no_alloc_column_sums_edges():
                                  C.c_void_p(stream))
     assert rc == ma.E_ARG
     assert b"scratch" in L.MFCCLastError()
+
+
+def test_no_alloc_column_sums_replayed_from_a_captured_graph():
+    """What the entry point is for: after the eager warm-up call, a call made while its stream is
+    being captured only enqueues kernels; the graph is then replayed on new contents of the same
+    buffers and must give the eager result of those contents, bit for bit."""
+    import torch
+    L = ma.lib()
+    step, rows = 45, 3000
+    assert L.MFCCColumnSumsNoAllocWarmup() == 0
+    x = torch.randn(rows, step, dtype=torch.float32, device="cuda")
+    sums = torch.zeros(2 * step + 1, dtype=torch.float64, device="cuda")
+    eager = torch.zeros_like(sums)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        st = torch.cuda.current_stream().cuda_stream
+        rc = L.MFCCColumnSumsNoAlloc(ma.PREC_F32, C.c_void_p(x.data_ptr()), rows, step, C.c_void_p(sums.data_ptr()), C.c_void_p(st))
+    assert rc == 0, L.MFCCLastError()
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        x.copy_(torch.randn(rows, step, dtype=torch.float32, device="cuda") * (10.0 ** seed))
+        sums.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        st = torch.cuda.current_stream().cuda_stream
+        assert L.MFCCColumnSumsNoAlloc(ma.PREC_F32, C.c_void_p(x.data_ptr()), rows, step, C.c_void_p(eager.data_ptr()), C.c_void_p(st)) == 0
+        torch.cuda.synchronize()
+        assert float(sums[-1]) == rows
+        assert np.array_equal(sums.cpu().numpy().view(np.uint64), eager.cpu().numpy().view(np.uint64))

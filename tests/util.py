@@ -41,13 +41,37 @@ def _note(kind, err, tol):
         ACHIEVED[kind] = (err, tol)
 
 
+# Single-precision tolerances per column kind: (absolute, relative to the largest magnitude of the
+# kind's static columns).  The stated bars are 1e-4 absolute on log-mel and 1e-5 relative on
+# cepstra; the others (and the absolute floor under the cepstral one, which a sum of P log-mel
+# errors scaled by sqrt(2/P) needs when every cepstrum is small) are set from what the kernels
+# achieve over the whole suite, about twice to four times the largest error seen (the table
+# printed at the end of a run shows the margins).
+def kind_tolerance(kind, mx, kw, delta=False):
+    P = float(kw.get("bankNum", 1))
+    if kind in ("mel",):
+        return 1e-4
+    if kind == "energy":
+        return 2e-5
+    if kind == "cep":  # (stated: 1e-5 relative; held to 4e-6)
+        return max(4e-6 * mx, 1e-5 * float(np.sqrt(2.0 * P)))
+    if kind == "c0":   # sqrt(2/P) times the sum of P log-mel values: their errors add
+        return max(1e-6 * mx, 2.5e-5 * float(np.sqrt(2.0 * P)))
+    if kind == "zc":
+        return 1e-7 if delta else 6e-8  # static: the same count, the quotient rounded once to single precision
+    if kind in ("bright", "sub"):
+        return 6e-7
+    if kind == "fft":
+        return 1e-5 * max(mx, 1.0)
+    raise KeyError(kind)
+
+
 def assert_static_close(got, ref, kw, f64=False, delta=False, static_ref=None):
-    """Tolerances for the static block: log-mel / log-energy 1e-4 absolute; cepstra 1e-5 relative
-    to the largest cepstral magnitude of the matrix and C0 1e-5 relative to the largest C0; ZCR exact (the same crossing count,
-    the quotient rounded to single precision); brightness / sub-band
-    fractions 1e-5 absolute; debug FFT magnitudes 1e-5 relative to the largest magnitude.
-    In f64 mode everything must agree to 1e-9 (relative to magnitude).  delta=True: the block holds
-    regression deltas; they inherit the tolerances, except that a ZCR delta is 1e-6 absolute, and
+    """Tolerances for the static block (kind_tolerance): log-mel 1e-4 absolute; cepstra / C0 1e-5
+    relative to the largest cepstral / C0 magnitude of the matrix; ZCR exact (the same crossing
+    count, the quotient rounded to single precision); log energy, brightness / sub-band fractions
+    and debug FFT magnitudes as achieved.  In f64 mode everything must agree to 1e-9 (relative to
+    magnitude).  delta=True: the block holds regression deltas; they inherit the tolerances, and
     the relative ones (cepstra, magnitudes) stay relative to the static block `static_ref` the
     deltas were formed from (a delta is a difference of those values divided by a constant >= 2)."""
     kinds = column_kinds(kw) * kw.get("vecNum", 1)
@@ -69,13 +93,7 @@ def assert_static_close(got, ref, kw, f64=False, delta=False, static_ref=None):
         _note("f64 (relative)", rel, 1e-9)
         assert rel < 1e-9
         return
-    # cepstra: 1e-5 of the largest cepstral magnitude, but never tighter than a fifth of what the
-    # 1e-4 log-mel tolerance implies for a sum of P channels scaled by sqrt(2/P)
-    cep_floor = 2e-5 * float(np.sqrt(2.0 * kw.get("bankNum", 1)))
-    for kind, atol_of in (("mel", lambda x: 1e-4), ("energy", lambda x: 1e-4),
-                          ("cep", lambda x: max(1e-5 * x, cep_floor)), ("c0", lambda x: max(1e-5 * x, cep_floor)),
-                          ("zc", lambda x: 1e-6), ("bright", lambda x: 1e-5), ("sub", lambda x: 1e-5),
-                          ("fft", lambda x: 1e-5 * max(x, 1.0))):
+    for kind in ("mel", "energy", "cep", "c0", "zc", "bright", "sub", "fft"):
         m = kinds == kind
         if not m.any() or g.shape[0] == 0:
             continue
@@ -84,8 +102,49 @@ def assert_static_close(got, ref, kw, f64=False, delta=False, static_ref=None):
             assert np.array_equal(g[:, m], r[:, m].astype(np.float32).astype(np.float64))
             continue
         err = float(np.max(np.abs(g[:, m] - r[:, m])))
-        _note(kind + (" delta" if delta else ""), err, atol_of(mx))
-        assert err <= atol_of(mx), "%s%s: max error %g > %g" % (kind, " (delta block)" if delta else "", err, atol_of(mx))
+        tol = kind_tolerance(kind, mx, kw, delta)
+        _note(kind + (" delta" if delta else ""), err, tol)
+        assert err <= tol, "%s%s: max error %g > %g" % (kind, " (delta block)" if delta else "", err, tol)
+
+
+def assert_znorm_close(got, ref, raw, kw, f64=False):
+    """z-normalised matrices (every column (x - mean) / std over the utterance's frames, deltas
+    included).  raw: the reference's matrix before the normalisation.  An error e in a value, in
+    the column's mean and in its std moves z by at most e / std (1 + 1 + |z|), so column c is held
+    to kind_tolerance(kind of c) (2 + max |z_c|) / std_c; what is noted for the end-of-run table is
+    the error brought back to the un-normalised scale against the kind's own tolerance."""
+    assert got.shape == ref.shape == raw.shape
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    if got.shape[0] == 0:
+        return
+    base = column_kinds(kw) * kw.get("vecNum", 1)
+    vs = len(base)
+    orders = kw.get("regreOrder", 1)
+    rawf = np.where(np.isfinite(raw), raw, 0.0)
+    for o in range(orders):
+        for kind in sorted(set(base)):
+            cols = np.array([o * vs + i for i, k in enumerate(base) if k == kind])
+            x = raw[:, cols]
+            ok = np.all(np.isfinite(ref[:, cols]), axis=0) & np.all(np.isfinite(x), axis=0)
+            if not ok.any():
+                continue
+            cols, x = cols[ok], x[:, ok]
+            sd = x.std(axis=0)
+            zmax = np.max(np.abs(ref[:, cols]), axis=0)
+            err = np.max(np.abs(got[:, cols] - ref[:, cols]), axis=0)
+            if f64:
+                tol = 1e-9 * np.maximum(np.max(np.abs(x), axis=0), 1.0)
+            else:
+                mx = float(np.max(np.abs(rawf[:, [i for i, k in enumerate(base) if k == kind]])))
+                tol = kind_tolerance(kind, mx, kw, delta=o > 0)
+                if kind == "zc":
+                    tol = max(tol, 1e-7)
+            back = err * sd / (2.0 + zmax)  # the error on the un-normalised scale
+            worst = int(np.argmax(back / tol))
+            name = "znorm %s%s%s" % ("f64 " if f64 else "", kind, " delta" if o > 0 else "")
+            t = float(tol[worst]) if f64 else float(tol)
+            _note(name, float(back[worst]), t)
+            assert np.all(back <= tol), "%s: error %g (un-normalised scale) > %g" % (name, float(back[worst]), t)
 
 
 def run_product_batch(ma, cfg, pcm_list, channels, bps, device=0, pad=None):
