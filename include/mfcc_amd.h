@@ -245,6 +245,18 @@ int MFCCExtractRecording(const MFCCConfig *cfg, const void *pcm, int channels, i
                          int64_t numSamples, int numShards, const int *devices, void *features,
                          int64_t *numFrames);
 
+/* The exchange step of a frame-sharded recording between processes (one process per GPU, each with
+ * its own RCCL communicator of the same clique: ncclCommInitRank on the caller's side): valuesDev
+ * holds this rank's `count` partial sums -- doubles (the 2*step+1 z-norm column sums of
+ * MFCCShardColumnSums) or, with isInt64, 64-bit integers (the 4 channel sums of MFCCChannelSums) --
+ * and receives the totals: ncclAllGather into gatherDev (world * count * 8 bytes of device
+ * memory), then one kernel adds the ranks' vectors in rank order, so every rank holds
+ * bit-identical totals.  comm: an ncclComm_t.  Asynchronous on the stream.  The reference
+ * normalises one file in one thread (commented calls main.c:263-266; README.md:122); this is the
+ * step that lets one recording span GPUs.  MFCCExtractRecording uses it between its shards when
+ * they sit on distinct GPUs.  librccl.so.1 is loaded on first use. */
+int MFCCShardExchange(void *comm, int isInt64, void *valuesDev, int count, void *gatherDev, void *stream);
+
 /* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): the column sums of
  * MFCCShardColumnSums -- sum x, sum x^2 per column, then the row count, 2*step+1 doubles to

@@ -76,7 +76,7 @@ EXPORTS = [
     "MFCCContextPassbandText", "MFCCContextTables", "MFCCPlanCreate", "MFCCPlanCreateShard",
     "MFCCPlanDestroy", "MFCCShardGeometry", "MFCCPlanTotalRows", "MFCCPlanRowOffset", "MFCCPlanNumFrames",
     "MFCCPlanSampleBegin", "MFCCPlanSampleCount", "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows",
-    "MFCCExtractDevice", "MFCCExtractRecording", "MFCCColumnSumsNoAlloc", "MFCCColumnSumsNoAllocWarmup", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
+    "MFCCExtractDevice", "MFCCExtractRecording", "MFCCColumnSumsNoAlloc", "MFCCColumnSumsNoAllocWarmup", "MFCCShardExchange", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
     "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCDebugTuning", "MFCCSynthPcm", "MFCCSynthPcmAt", "MFCCFormatValue",
     "MFCCFFTDevice", "MFCCRealftDevice", "MFCCWave2FBankDevice", "MFCCFBank2MFCCDevice", "MFCCMel",
     "MFCCFBankTables", "MFCCWave2FBankTablesDevice", "MFCCFBank2MFCCDirectDevice",
@@ -141,6 +141,7 @@ def lib():
     L.MFCCExtractRecording.argtypes = [cfgp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, C.POINTER(C.c_int64)]
     L.MFCCColumnSumsNoAlloc.argtypes = [C.c_int, vp, C.c_int64, C.c_int, vp, vp]
     L.MFCCColumnSumsNoAllocWarmup.argtypes = []
+    L.MFCCShardExchange.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
     L.MFCCShardNormalize.argtypes = [vp, vp, vp, vp, vp]
     L.MFCCChannelSums.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp]
     L.MFCCPlanEnableTiming.argtypes = [vp, C.c_int]

@@ -255,6 +255,8 @@ struct Tuning {
     int noFinishReg = 0;   // whole-utterance finishing kernel without its register variant
     int noFusedDelta = 0;  // one regression pass per order
     int leanChunk = 0;     // tiles per chunk of the pipelined 256-point kernel (0: heuristic, -1: fixed ranges)
+    int pinHost = 0;       // MFCCExtractRecording page-locks the caller's PCM and feature buffers for the call (hipHostRegister): 0 = from 64 MiB of PCM on, 1 = always, -1 = never
+    int rccl = 0;          // MFCCExtractRecording's sums exchange: 0 = RCCL when the shards sit on distinct GPUs, 1 = always RCCL, -1 = always host memory
     int debug = 0;         // print the plan's choices to stderr
 };
 Tuning g_tune;
@@ -278,7 +280,7 @@ extern "C" int MFCCDebugTuning(const char *key, int value)
         {"tileTables", &Tuning::tileTables}, {"tileBlocks", &Tuning::tileBlocks}, {"melPieces", &Tuning::melPieces},
         {"noMelMatrix", &Tuning::noMelMatrix}, {"leanWaves", &Tuning::leanWaves}, {"blocksPerCu", &Tuning::blocksPerCu}, {"noUttFinish", &Tuning::noUttFinish},
         {"noFinishReg", &Tuning::noFinishReg}, {"noFusedDelta", &Tuning::noFusedDelta}, {"leanChunk", &Tuning::leanChunk},
-        {"debug", &Tuning::debug}};
+        {"rccl", &Tuning::rccl}, {"pinHost", &Tuning::pinHost}, {"debug", &Tuning::debug}};
     for (const auto &k : keys)
         if (!strcmp(key, k.name)) {
             g_tune.*(k.field) = value;
@@ -2408,9 +2410,43 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
     std::vector<std::string> message((size_t)S);
     std::atomic<bool> failed(false);
     ShardBarrier barrier(S);
+    const size_t nSums = (size_t)2 * step + 1;
+
+    // The two exchanges (integer channel sums for the zero-mean option, z-norm column sums) go over
+    // RCCL -- all-gather on the GPUs, then a rank-ordered sum on every GPU (MFCCShardExchange) -- when
+    // the shards sit on distinct GPUs; shards that share a GPU (RCCL refuses one device twice in a
+    // communicator) exchange through host memory, added in the same order.
+    std::vector<int> devOf((size_t)S);
+    for (int g = 0; g < S; ++g) devOf[(size_t)g] = devices ? devices[g] : (current + g) % visible;
+    bool distinct = true;
+    for (int g = 0; g < S; ++g)
+        for (int k = 0; k < g; ++k) distinct = distinct && devOf[(size_t)g] != devOf[(size_t)k];
+    const int rcclMode = tuning().rccl;
+    const bool needExchange = cfg.znormFlag || cfg.zeroMeanSigFlag;
+    bool useRccl = needExchange && rcclMode >= 0 && distinct && (S > 1 || rcclMode > 0);
+    if (rcclMode > 0 && needExchange && !distinct)
+        return set_error("the RCCL exchange needs every shard on its own GPU"), MFCC_E_ARG;
+    std::vector<void *> comms((size_t)S, nullptr);
+    if (useRccl) {
+        rc = rccl_load();
+        if (!rc) rc = rccl_comm_init_all(comms.data(), S, devOf.data());
+        if (rc && rcclMode > 0) return rc;
+        if (rc) useRccl = false; // (no RCCL on this machine: host memory carries the sums)
+        (void)hipSetDevice(current);
+    }
+
+    // Page-locking the caller's buffers for the call makes the shards' copies true DMA transfers that
+    // overlap the other shards' kernels (several shards per GPU form a pipeline of their own).
+    bool pinnedPcm = false, pinnedOut = false;
+    const int pinMode = tuning().pinHost;
+    if (pinMode > 0 || (pinMode == 0 && (size_t)(numSamples * bpi) >= ((size_t)64 << 20))) {
+        pinnedPcm = hipHostRegister(const_cast<void *>(pcm), (size_t)(numSamples * bpi), hipHostRegisterDefault) == hipSuccess;
+        pinnedOut = hipHostRegister(features, (size_t)T * step * el, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+    }
 
     auto shard = [&](int g) {
-        const int dev = devices ? devices[g] : (current + g) % visible;
+        const int dev = devOf[(size_t)g];
         const int64_t fb = T * g / S, fe = T * (g + 1) / S;
         int64_t sb = 0, sc = 0, rows = 0, ownBegin = 0, ownRows = 0;
         int lead = 0;
@@ -2421,7 +2457,7 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
         const int64_t upBegin = empty ? partBegin : std::min(sb, partBegin);
         const int64_t upEnd = std::max(empty ? partEnd : sb + sc, partEnd);
         CtxRef ctx;
-        DevBuf dPcm, dOut, dSums;
+        DevBuf dPcm, dOut, dSums, dGather;
         MFCCPlan *plan = nullptr;
         hipStream_t st = nullptr;
         auto fail = [&](int code) {
@@ -2442,7 +2478,9 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
             if (r) fail(r), ok = false;
         }
         if (ok) ok = hip_ok(hipMalloc(&dPcm.p, (size_t)std::max<int64_t>((upEnd - upBegin) * bpi, 16) + 16)) &&
-                     hip_ok(hipMalloc(&dSums.p, ((size_t)2 * step + 1) * sizeof(double) + 64)) &&
+                     hip_ok(hipMalloc(&dSums.p, nSums * sizeof(double) + 64)) &&
+                     hip_ok(hipMemsetAsync(dSums.p, 0, nSums * sizeof(double) + 64, st)) &&
+                     (!useRccl || hip_ok(hipMalloc(&dGather.p, (size_t)S * nSums * sizeof(double)))) &&
                      hip_ok(hipMemcpyAsync(dPcm.p, static_cast<const unsigned char *>(pcm) + upBegin * bpi,
                                            (size_t)((upEnd - upBegin) * bpi), hipMemcpyHostToDevice, st));
         chanSums[(size_t)g] = {0, 0, 0, 0};
@@ -2450,16 +2488,27 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
             const int r = MFCCChannelSums(ctx.get(), dPcm.p, channels, bytesPerSample, partBegin - upBegin,
                                           partEnd - partBegin, static_cast<int64_t *>(dSums.p), st);
             if (r) fail(r), ok = false;
-            else
+            else if (!useRccl)
                 ok = hip_ok(hipMemcpyAsync(chanSums[(size_t)g].data(), dSums.p, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st)) &&
                      hip_ok(hipStreamSynchronize(st));
         }
         barrier.wait();
         // phase 2: plan, static features and deltas, column sums
         int64_t total2[4] = {0, 0, 0, 0};
-        for (int k = 0; k < S; ++k)
-            for (int j = 0; j < 4; ++j) total2[j] += chanSums[(size_t)k][(size_t)j];
         ok = ok && !failed;
+        if (cfg.zeroMeanSigFlag && useRccl) {
+            if (ok) { // (failed is the same for every shard after the barrier: all of them enter the collective, or none)
+                const int r = MFCCShardExchange(comms[(size_t)g], 1, dSums.p, 4, dGather.p, st);
+                if (r) fail(r), ok = false;
+                else
+                    ok = hip_ok(hipMemcpyAsync(total2, dSums.p, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st)) &&
+                         hip_ok(hipStreamSynchronize(st));
+            }
+        } else {
+            for (int k = 0; k < S; ++k)
+                for (int j = 0; j < 4; ++j) total2[j] += chanSums[(size_t)k][(size_t)j];
+        }
+        if (ok && useRccl && cfg.znormFlag) ok = hip_ok(hipMemsetAsync(dSums.p, 0, nSums * sizeof(double), st)); // (an empty shard adds zeros)
         if (ok && !empty) {
             int r = MFCCPlanCreateShard(ctx.get(), channels, bytesPerSample, numSamples, fb, fe,
                                         cfg.zeroMeanSigFlag ? total2 : nullptr, &plan);
@@ -2468,9 +2517,8 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
             if (!r && ok) r = MFCCExtractDevice(ctx.get(), plan, shardPcm, (size_t)(sc * bpi), dOut.p, st);
             if (!r && ok && cfg.znormFlag) {
                 r = MFCCShardColumnSums(ctx.get(), plan, dOut.p, static_cast<double *>(dSums.p), st);
-                if (!r)
-                    ok = hip_ok(hipMemcpyAsync(colSums[(size_t)g].data(), dSums.p, ((size_t)2 * step + 1) * sizeof(double),
-                                               hipMemcpyDeviceToHost, st)) &&
+                if (!r && !useRccl)
+                    ok = hip_ok(hipMemcpyAsync(colSums[(size_t)g].data(), dSums.p, nSums * sizeof(double), hipMemcpyDeviceToHost, st)) &&
                          hip_ok(hipStreamSynchronize(st));
             }
             if (r) fail(r), ok = false;
@@ -2478,14 +2526,20 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
         barrier.wait();
         // phase 3: normalise with the totals, own rows back to the host
         ok = ok && !failed;
+        if (ok && cfg.znormFlag && useRccl) {
+            const int r = MFCCShardExchange(comms[(size_t)g], 0, dSums.p, (int)nSums, dGather.p, st);
+            if (r) fail(r), ok = false;
+        }
         if (ok && !empty) {
             int r = MFCC_OK;
             if (cfg.znormFlag) {
-                std::vector<double> tot((size_t)2 * step + 1, 0.0);
-                for (int k = 0; k < S; ++k)
-                    for (size_t j = 0; j < tot.size(); ++j) tot[j] += colSums[(size_t)k][j];
-                ok = hip_ok(hipMemcpyAsync(dSums.p, tot.data(), tot.size() * sizeof(double), hipMemcpyHostToDevice, st)) &&
-                     hip_ok(hipStreamSynchronize(st)); // (tot leaves scope)
+                if (!useRccl) {
+                    std::vector<double> tot(nSums, 0.0);
+                    for (int k = 0; k < S; ++k)
+                        for (size_t j = 0; j < tot.size(); ++j) tot[j] += colSums[(size_t)k][j];
+                    ok = hip_ok(hipMemcpyAsync(dSums.p, tot.data(), tot.size() * sizeof(double), hipMemcpyHostToDevice, st)) &&
+                         hip_ok(hipStreamSynchronize(st)); // (tot leaves scope)
+                }
                 if (ok) r = MFCCShardNormalize(ctx.get(), plan, dOut.p, static_cast<const double *>(dSums.p), st);
             }
             if (!r && ok)
@@ -2495,6 +2549,7 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
                      hip_ok(hipStreamSynchronize(st));
             if (r) fail(r);
         }
+        if (ok && useRccl) ok = hip_ok(hipStreamSynchronize(st)); // (an empty shard's part of the collectives)
         if (plan) MFCCPlanDestroy(plan);
         if (st) (void)hipStreamDestroy(st);
     };
@@ -2502,6 +2557,9 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
     for (int g = 1; g < S; ++g) threads.emplace_back(shard, g);
     shard(0);
     for (auto &th : threads) th.join();
+    for (void *cm : comms) rccl_comm_destroy(cm);
+    if (pinnedPcm) (void)hipHostUnregister(const_cast<void *>(pcm));
+    if (pinnedOut) (void)hipHostUnregister(features);
     (void)hipSetDevice(current);
     for (int g = 0; g < S; ++g)
         if (status[(size_t)g] != MFCC_OK) return set_error("shard %d: %s", g, message[(size_t)g].c_str()), status[(size_t)g];

@@ -40,6 +40,12 @@ struct WavInfo {
 int wav_parse(const unsigned char *f, size_t len, WavInfo &w);
 int read_file(const char *path, std::vector<unsigned char> &out);
 
+// RCCL, loaded on first use (exchange.hip).  rccl_comm_init_all: one communicator per listed device
+// (ncclCommInitAll; the devices must be distinct).
+int rccl_load();
+int rccl_comm_init_all(void **comms, int n, const int *devices);
+void rccl_comm_destroy(void *comm);
+
 // printf-identical "%f" / "%e" of one value into out (>= 400 bytes); returns the length.
 int fmt_f6(double x, char *out);
 int fmt_e6(double x, char *out);

@@ -1029,6 +1029,54 @@ def test_recording_over_several_shards_from_one_process(oracle, zero_mean):
     assert ma.extract_recording(cfg, pcm[:600], 2, 3, num_shards=2, devices=[0, 0]).shape[0] == 0
 
 
+def test_recording_exchange_over_rccl_equals_the_host_exchange(oracle, tuning):
+    """The exchanges of MFCCExtractRecording (integer channel sums, z-norm column sums) through the
+    RCCL branch -- ncclCommInitAll, ncclAllGather on device buffers, rank-ordered sum kernel --
+    forced on for the one shard this box's one GPU allows, bit for bit against the host-memory
+    branch and within tolerance of the oracle; two shards on one GPU are refused in that mode."""
+    kw = dict(CONFIGS["c5"], zeroMeanSigFlag=1)
+    n = 44100 * 2 + 321
+    pcm = _pcm(n, 2, 3, 92, 44100)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 2, 3)
+    for prec, f64 in ((ma.PREC_F32, False), (ma.PREC_F64, True)):
+        cfg = ma.make_config(precision=prec, **kw)
+        tuning(rccl=-1)
+        host = ma.extract_recording(cfg, pcm, 2, 3, num_shards=1)
+        tuning(rccl=1)
+        over = ma.extract_recording(cfg, pcm, 2, 3, num_shards=1)
+        assert np.array_equal(host.view(np.uint8), over.view(np.uint8))
+        _compare(over.astype(np.float64), ref, kw, f64, src=(oracle, pcm, 2, 3))
+    with pytest.raises(ma.MFCCError):
+        ma.extract_recording(cfg, pcm, 2, 3, num_shards=2, devices=[0, 0])
+
+
+def test_shard_exchange_entry_point_on_a_one_rank_communicator():
+    """MFCCShardExchange as a multi-process caller uses it: a communicator made by the caller (here
+    ncclCommInitAll over the one device, through librccl's C ABI), values in device memory; with
+    one rank the totals equal the rank's own values, for doubles and for 64-bit integers."""
+    import ctypes as C
+    import torch
+    rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    L = ma.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vals = torch.arange(613, dtype=torch.float64, device="cuda") * 0.37 - 5.0
+    want = vals.clone()
+    gather = torch.zeros(613, dtype=torch.float64, device="cuda")
+    assert L.MFCCShardExchange(comm, 0, C.c_void_p(vals.data_ptr()), 613, C.c_void_p(gather.data_ptr()), st) == 0, L.MFCCLastError()
+    torch.cuda.synchronize()
+    assert torch.equal(vals, want) and torch.equal(gather, want)
+    iv = torch.tensor([2 ** 40 + 7, -3, 0, 2 ** 62], dtype=torch.int64, device="cuda")
+    ig = torch.zeros(4, dtype=torch.int64, device="cuda")
+    assert L.MFCCShardExchange(comm, 1, C.c_void_p(iv.data_ptr()), 4, C.c_void_p(ig.data_ptr()), st) == 0
+    torch.cuda.synchronize()
+    assert iv.tolist() == [2 ** 40 + 7, -3, 0, 2 ** 62] == ig.tolist()
+    assert L.MFCCShardExchange(None, 0, C.c_void_p(vals.data_ptr()), 613, C.c_void_p(gather.data_ptr()), st) == ma.E_ARG
+    rccl.ncclCommDestroy(comm)
+
+
 def test_command_line_program_matches_the_per_file_entry_point(tmp_path):
     """The drop-in program (`mfcc config.ini`, README.md:26) on an example/config.ini-shaped run:
     its files equal MFCCWapper's byte for byte, and its console carries the reference's lines

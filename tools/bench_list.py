@@ -2,7 +2,8 @@
 """End-to-end rate of the drop-in list entry point (MFCCWapperList = the reference's main loop,
 main.c:173-289): WAV files on disk in, feature files on disk out, nothing resident beforehand.
 
-  python tools/bench_list.py [--files 2000] [--seconds 10] [--save b,n,f] [--dir <repo>/.bench_list_tmp]
+  python tools/bench_list.py [--files 2000] [--seconds 10] [--save b,n,f] [--preset c2|mfcc39] [--precision f64|f32]
+                             [--dir <repo>/.bench_list_tmp]
 
 Writes synthetic 16-bit mono WAV files, one ini per save type, and prints one JSON line per save
 type with files/s and frames/s (file reads, H2D, kernels, D2H and writers all inside the timed
@@ -40,6 +41,9 @@ def main():
     ap.add_argument("--dir", default=os.path.join(REPO, ".bench_list_tmp"))
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--preset", default="mfcc39", choices=["mfcc39", "c2"],
+                    help="mfcc39: 12 MFCC + C0, deltas and delta-deltas; c2: the 40-bin log-mel benchmark configuration")
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64"])
     args = ap.parse_args()
     rate, wlen, inc = 16000, 400, 160
     n = int(args.seconds * rate)
@@ -61,9 +65,15 @@ def main():
                                           os.path.join(args.dir, "out", "%06d.%s" % (i, save))))
             ini = os.path.join(args.dir, "config_%s.ini" % save)
             with open(ini, "w") as f:
-                f.write("[Frame]\nsampleRate = %d\nwlen = %d\ninc = %d\nsaveType = %s\nfileList = %s\n"
-                        "[MFCC]\nMFCCNum = 12\nMFCC0thFlag = 1\n[Regression]\nregreOrder = 3\ndelwin = 2\n"
-                        "[IO]\nnumThreads = %d\n" % (rate, wlen, inc, save, lst, args.threads))
+                if args.preset == "c2":
+                    body = ("[Frame]\nsampleRate = %d\nwlen = %d\ninc = %d\nlowpassfre = 20\nhipassfre = 8000\n"
+                            "preemphasise = 0.97\nsaveType = %s\nfileList = %s\n[MFCC]\nfbankFlag = 1\nbankNum = 40\n"
+                            % (rate, wlen, inc, save, lst))
+                else:
+                    body = ("[Frame]\nsampleRate = %d\nwlen = %d\ninc = %d\nsaveType = %s\nfileList = %s\n"
+                            "[MFCC]\nMFCCNum = 12\nMFCC0thFlag = 1\n[Regression]\nregreOrder = 3\ndelwin = 2\n"
+                            % (rate, wlen, inc, save, lst))
+                f.write(body + "[IO]\nnumThreads = %d\nprecision = %s\n" % (args.threads, args.precision))
             os.environ["MFCC_QUIET"] = "1"
             best = None
             for _ in range(args.repeat):
@@ -73,7 +83,7 @@ def main():
                 assert rc == 0, (rc, ma.lib().MFCCLastError())
                 best = dt if best is None else min(best, dt)
             out0 = os.path.join(args.dir, "out", "%06d.%s" % (0, save))
-            print(json.dumps({"entry": "MFCCWapperList", "saveType": save, "files": args.files,
+            print(json.dumps({"entry": "MFCCWapperList", "preset": args.preset, "precision": args.precision, "saveType": save, "files": args.files,
                               "seconds_per_file": args.seconds, "wall_s": round(best, 4),
                               "files_per_s": round(args.files / best, 1),
                               "frames_per_s": round(args.files * frames / best, 1),
