@@ -90,6 +90,11 @@ struct MFCCPlan {
     double *dBlockPartial = nullptr;
     // whole-utterance finishing pass (deltas + z-norm from compact static rows), see finish.hip
     bool uttFinish = false;
+    bool finStream = false;     // ... by the segment-streaming kernels (any utterance length) instead of the whole-utterance-in-LDS one
+    int32_t *dSegs = nullptr, *dSegBegin = nullptr; // segments {utterance, first row}, first segment of every utterance
+    double *dSegPartial = nullptr, *dSegStats = nullptr;
+    int numSegs = 0;
+    int strColBlock = 0, strColBlocks = 0, strChunkRows = 0, strWaveElems = 0, strRedOffset = 0;
     int regRows = kRegRows; // rows per block of the regression / fused delta kernels
     void *dStatics = nullptr; // totalRows x vSize
     int finSubRows = 0, finStaticElems = 0, finRedOffset = 0, finRegRows = 0;
@@ -253,6 +258,8 @@ struct Tuning {
     int blocksPerCu = 0;   // resident workgroups per CU (0: heuristic)
     int noUttFinish = 0;   // deltas / z-norm by the row-block kernels even for short utterances
     int noFinishReg = 0;   // whole-utterance finishing kernel without its register variant
+    int finish = 0;        // batch plans' deltas / z-norm: 0 heuristic, 1 whole-utterance-in-LDS kernel if it fits, 2 streaming kernel, 3 row blocks
+    int streamRows = 0;    // rows per chunk of the streaming finishing kernel (0: heuristic)
     int noFusedDelta = 0;  // one regression pass per order
     int leanChunk = 0;     // tiles per chunk of the pipelined 256-point kernel (0: heuristic, -1: fixed ranges)
     int pinHost = 0;       // MFCCExtractRecording page-locks the caller's PCM and feature buffers for the call (hipHostRegister): 0 = from 64 MiB of PCM on, 1 = always, -1 = never
@@ -279,7 +286,7 @@ extern "C" int MFCCDebugTuning(const char *key, int value)
         {"noLean", &Tuning::noLean}, {"pplog", &Tuning::pplog}, {"tileFrames", &Tuning::tileFrames},
         {"tileTables", &Tuning::tileTables}, {"tileBlocks", &Tuning::tileBlocks}, {"melPieces", &Tuning::melPieces},
         {"noMelMatrix", &Tuning::noMelMatrix}, {"leanWaves", &Tuning::leanWaves}, {"blocksPerCu", &Tuning::blocksPerCu}, {"noUttFinish", &Tuning::noUttFinish},
-        {"noFinishReg", &Tuning::noFinishReg}, {"noFusedDelta", &Tuning::noFusedDelta}, {"leanChunk", &Tuning::leanChunk},
+        {"noFinishReg", &Tuning::noFinishReg}, {"finish", &Tuning::finish}, {"streamRows", &Tuning::streamRows}, {"noFusedDelta", &Tuning::noFusedDelta}, {"leanChunk", &Tuning::leanChunk},
         {"rccl", &Tuning::rccl}, {"pinHost", &Tuning::pinHost}, {"debug", &Tuning::debug}};
     for (const auto &k : keys)
         if (!strcmp(key, k.name)) {
@@ -1074,13 +1081,45 @@ static int finish_plan(MFCCPlan *p)
     // Whole-utterance finishing pass: batch plans whose longest utterance's static rows fit the
     // LDS budget (two workgroups per CU) beside the sub-tile buffers.
     p->uttFinish = false;
-    if (!p->shard && c->cfg.regreOrder <= 3 && (c->cfg.regreOrder >= 2 || c->cfg.znormFlag) && c->vSize <= kBlock &&
-        p->totalRows > 0 && !tune.noUttFinish) {
+    p->finStream = false;
+    const bool wantFinish = !p->shard && c->cfg.regreOrder <= 3 && (c->cfg.regreOrder >= 2 || c->cfg.znormFlag) &&
+                            p->totalRows > 0 && !tune.noUttFinish && tune.finish != 3;
+    if (wantFinish) {
         const size_t elb = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
         int64_t maxFrames = 1;
         for (const UttDesc &d : p->utts) maxFrames = std::max<int64_t>(maxFrames, d.numFrames);
+        // Segment-streaming kernels (any utterance length; the partition of an utterance's rows does not
+        // depend on the batch): the default whenever their LDS regions fit.
+        size_t strLds = 0;
+        const bool strFits = stream_finish_geometry(c->vSize, c->cfg.regreOrder, c->cfg.delwin, (int)elb, tune.streamRows, &p->strColBlock,
+                                                    &p->strColBlocks, &p->strChunkRows, &p->strWaveElems, &p->strRedOffset, &strLds);
+        if (strFits && (tune.finish == 2 || tune.finish == 0)) {
+            p->uttFinish = p->finStream = true;
+            p->finLds = strLds;
+            const int segRows = stream_finish_seg_chunks() * p->strChunkRows;
+            std::vector<int32_t> segs, segBegin(nu + 1, 0);
+            for (size_t u = 0; u < nu; ++u) {
+                segBegin[u] = (int32_t)(segs.size() / 2);
+                for (int r = 0; r < p->utts[u].numFrames; r += segRows) {
+                    segs.push_back((int32_t)u);
+                    segs.push_back(r);
+                }
+            }
+            segBegin[nu] = (int32_t)(segs.size() / 2);
+            p->numSegs = segBegin[nu];
+            HIP_TRY(hipMalloc((void **)&p->dSegs, std::max<size_t>(segs.size(), 2) * sizeof(int32_t)));
+            if (!segs.empty()) HIP_TRY(hipMemcpy(p->dSegs, segs.data(), segs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void **)&p->dSegBegin, segBegin.size() * sizeof(int32_t)));
+            HIP_TRY(hipMemcpy(p->dSegBegin, segBegin.data(), segBegin.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (c->cfg.znormFlag) {
+                HIP_TRY(hipMalloc((void **)&p->dSegPartial, std::max<size_t>((size_t)p->numSegs, 1) * 2 * c->step * sizeof(double)));
+                HIP_TRY(hipMalloc((void **)&p->dSegStats, std::max<size_t>(nu, 1) * 2 * c->step * sizeof(double)));
+            }
+        }
+        // Whole-utterance-in-LDS kernel: batch plans whose longest utterance's static rows fit the LDS
+        // budget (two workgroups per CU) beside the sub-tile buffers.
         const size_t statics = (size_t)maxFrames * c->vSize;
-        for (int sr = 64; sr >= 8 && !p->uttFinish; sr /= 2) {
+        for (int sr = 64; sr >= 8 && !p->uttFinish && c->vSize <= kBlock; sr /= 2) {
             const size_t elems = statics + (size_t)(sr + 2 * c->cfg.delwin) * c->vSize + (size_t)sr * c->step;
             const size_t redOff = (elems * elb + 15) & ~(size_t)15;
             const size_t total = redOff + (2 * (size_t)kFinishBlock + 2 * (size_t)c->step) * sizeof(double);
@@ -1092,7 +1131,7 @@ static int finish_plan(MFCCPlan *p)
                 p->finLds = total;
             }
         }
-        if (p->uttFinish) { // register variant: sub-tiles of rowLanes rows, at most kFinishRegRows per lane
+        if (p->uttFinish && !p->finStream) { // register variant: sub-tiles of rowLanes rows, at most kFinishRegRows per lane
             const int rowLanes = kFinishBlock / std::min(kFinishBlock, c->vSize);
             p->finRegRows = (maxFrames <= (int64_t)kFinishRegRows * rowLanes && !tune.noFinishReg) ? 1 : 0;
             // (its two first-delta buffers of rowLanes + 2 delwin rows must fit where the sub-tile buffers are)
@@ -1102,7 +1141,9 @@ static int finish_plan(MFCCPlan *p)
         }
         if (tune.debug)
             fprintf(stderr, "mfcc plan: deltas / z-norm by %s (longest utterance %lld frames, %zu B of LDS)\n",
-                    !p->uttFinish ? "row blocks" : (p->finRegRows ? "whole-utterance kernel, registers" : "whole-utterance kernel, two sweeps"),
+                    !p->uttFinish ? "row blocks"
+                                  : (p->finStream ? "segment-streaming kernels"
+                                                  : (p->finRegRows ? "whole-utterance kernel, registers" : "whole-utterance kernel, two sweeps")),
                     (long long)maxFrames, p->finLds);
         if (p->uttFinish)
             HIP_TRY(hipMalloc(&p->dStatics, std::max<size_t>((size_t)p->totalRows * c->vSize * elb, 16)));
@@ -1265,6 +1306,10 @@ extern "C" void MFCCPlanDestroy(MFCCPlan *p)
     (void)hipFree(p->dMelW64);
     (void)hipFree(p->dBlockPartial);
     (void)hipFree(p->dStatics);
+    (void)hipFree(p->dSegs);
+    (void)hipFree(p->dSegBegin);
+    (void)hipFree(p->dSegPartial);
+    (void)hipFree(p->dSegStats);
     (void)hipFree(p->dMelMeta);
     (void)hipFree(p->dWork);
     (void)hipFree(p->dChunkUtt);
@@ -1543,6 +1588,19 @@ static int run_finish(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
     a.znorm = c->cfg.znormFlag ? 1 : 0;
     a.regRows = p->finRegRows;
     a.sigmaT2 = 2.0 * sigmaT2;
+    if (p->finStream) {
+        StreamArgs<T> sa;
+        memset(&sa, 0, sizeof sa);
+        sa.statics = a.statics, sa.out = a.out, sa.utts = a.utts, sa.segs = p->dSegs, sa.segBegin = p->dSegBegin;
+        sa.numSegs = p->numSegs, sa.numUtts = p->numUtts;
+        sa.vSize = a.vSize, sa.step = a.step, sa.delwin = a.delwin, sa.znorm = a.znorm;
+        sa.colBlock = p->strColBlock, sa.numColBlocks = p->strColBlocks, sa.chunkRows = p->strChunkRows;
+        sa.waveElems = p->strWaveElems, sa.redOffset = p->strRedOffset, sa.sigmaT2 = a.sigmaT2;
+        sa.partial = p->dSegPartial, sa.stats = p->dSegStats;
+        const int rc = launch_seg_finish(c->cfg.precision, &sa, c->cfg.regreOrder, p->finLds, stream);
+        if (rc) return set_error("segment finishing kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
+        return MFCC_OK;
+    }
     const int rc = launch_utt_finish(c->cfg.precision, &a, c->cfg.regreOrder, p->numUtts, p->finLds, stream);
     if (rc) return set_error("finishing kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
     return MFCC_OK;

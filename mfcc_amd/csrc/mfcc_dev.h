@@ -140,6 +140,29 @@ struct FinishArgs {
     double sigmaT2;
 };
 
+// Segment-streaming finishing pass of batch plans (stream_finish.hip)
+template <typename T>
+struct StreamArgs {
+    const T *statics;       // totalRows x vSize, compact
+    T *out;                 // totalRows x step
+    const UttDesc *utts;
+    const int32_t *segs;    // numSegs x {utterance, first row of the segment inside it}
+    const int32_t *segBegin;// numUtts + 1: first segment of every utterance
+    int numSegs, numUtts;
+    int vSize, step, delwin, znorm;
+    int colBlock, numColBlocks; // columns per workgroup (<= 64), workgroups per segment
+    int chunkRows;          // rows a wave finishes per chunk (a segment: stream_finish_seg_chunks() chunks)
+    int waveElems;          // LDS elements of one wave's region
+    int redOffset;          // byte offset of the reduction scratch in LDS
+    double sigmaT2;
+    double *partial;        // numSegs x 2*step: column sums and sums of squares of every segment
+    double *stats;          // numUtts x 2*step: mean | 1 / std
+};
+int stream_finish_seg_chunks();
+bool stream_finish_geometry(int vSize, int orders, int delwin, int elemBytes, int wantRows, int *colBlock, int *numColBlocks,
+                            int *chunkRows, int *waveElems, int *redOffset, size_t *ldsBytes);
+int launch_seg_finish(int precision, const void *args, int orders, size_t ldsBytes, void *stream);
+
 template <typename T>
 struct StatArgs {
     T *data;

@@ -76,14 +76,14 @@ def _compare(got, ref, kw, f64, src=None):
                             static_ref=ref[:, :vs] if o > 0 else None)
 
 
-@pytest.mark.parametrize("finish", ["utterance", "blocks"])
+@pytest.mark.parametrize("finish", ["utterance", "blocks", "stream"])
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 @pytest.mark.parametrize("name", ["c2", "c3", "c4", "c1a", "c1b", "c5"])
 def test_named_configs_match_oracle(oracle, name, precision, finish, tuning):
-    """finish: deltas and z-norm by the whole-utterance kernel (short utterances) or by the
-    row-block kernels (what long utterances take; forced here through the noUttFinish tuning key)."""
-    if finish == "blocks":
-        tuning(noUttFinish=1)
+    """finish: deltas and z-norm by the whole-utterance-in-LDS kernel (small batches of short
+    utterances), by the row-block kernels (small batches with long utterances) or by the streaming
+    whole-utterance kernel (wide batches); each forced here through the `finish` tuning key."""
+    tuning(finish={"utterance": 1, "blocks": 3, "stream": 2}[finish])
     kw = CONFIGS[name]
     ch, bps = _layout(kw)
     n = kw["sampleRate"] + 123  # ~1 s: several tiles, first (general) and later (fast) unpack paths
@@ -184,9 +184,12 @@ def test_random_configurations(oracle, seed, tuning):
     """Seeded random walk over the option space (frame geometry, channel layouts, feature flags,
     delta orders and windows, z-norm, batches of ragged utterances at odd byte offsets): whichever
     kernel mode, tile geometry and delta path the plan picks must agree with the oracle.  Every
-    third seed takes the row-block delta / z-norm kernels instead of the whole-utterance one."""
+    third seed takes the row-block delta / z-norm kernels instead of the whole-utterance one, every
+    third the streaming whole-utterance kernel (where its LDS regions fit; else the plan falls back)."""
     if seed % 3 == 2:
         tuning(noUttFinish=1)
+    if seed % 3 == 1:
+        tuning(finish=2, streamRows=(0, 16, 8)[seed % 9 // 3])
     rng = np.random.default_rng(1000 + seed)
     sr = int(rng.choice([8000, 16000, 44100]))
     wlen = int(rng.choice([64, 200, 256, 400, 441, 512, 800, 1024, 1764, 2048]))
@@ -224,15 +227,18 @@ def test_random_configurations(oracle, seed, tuning):
                 _compare(got, ref, kw, f64, src=(oracle, p, ch, bps))
 
 
-@pytest.mark.parametrize("finish", ["utterance", "blocks", "too long"])
+@pytest.mark.parametrize("finish", ["utterance", "blocks", "too long", "stream", "stream, long"])
 def test_ragged_batch_and_edge_lengths(oracle, finish, tuning):
     """Empty, shorter than a window, exactly one window, one sample short of two frames, long;
-    with the whole-utterance finishing kernel, with the row-block kernels forced, and with one
-    utterance too long for the former (which moves the whole plan to the latter)."""
+    with the whole-utterance finishing kernel, with the row-block kernels forced, with one
+    utterance too long for the former (which moves the whole plan to the latter), and with the
+    streaming kernel (chunk sizes 8 and 32, utterances shorter than a chunk and of many chunks)."""
     if finish == "blocks":
         tuning(noUttFinish=1)
+    if finish.startswith("stream"):
+        tuning(finish=2, streamRows=8 if finish == "stream" else 0)
     kw = CONFIGS["c3"]
-    lens = [0, 1, 399, 400, 559, 560, 561, 5000, 16000, 401, 33333] + ([400 + 160 * 2500] if finish == "too long" else [])
+    lens = [0, 1, 399, 400, 559, 560, 561, 5000, 16000, 401, 33333] + ([400 + 160 * 2500] if finish in ("too long", "stream, long") else [])
     pcms = [_pcm(n, 1, 2, 100 + i, 16000) for i, n in enumerate(lens)]
     cfg = ma.make_config(precision=ma.PREC_F32, **kw)
     got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 1, 2)
@@ -859,9 +865,9 @@ def test_options_the_reference_leaves_off_in_the_extraction_path(oracle, name, o
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 @pytest.mark.parametrize("name", ["c3", "c1a"])
-def test_an_utterance_gives_the_same_bits_alone_and_beside_a_long_neighbour(name, precision):
-    """The delta / z-norm kernel is chosen from the longest utterance of a batch (whole-utterance
-    kernel in registers or in two sweeps, or the row-block kernels): one file must come out
+def test_an_utterance_gives_the_same_bits_alone_and_beside_a_long_neighbour(name, precision, tuning):
+    """The delta / z-norm kernel is chosen from the batch (whole-utterance kernel in registers or in
+    two sweeps, the row-block kernels, or -- wide batches -- the streaming kernel): one file must come out
     bit-identical whatever its batch neighbours are (MFCCWapperList batches, MFCCWapper does not).
     One exception is measured here instead: double-precision z-normalised rows, whose column sums
     the variants add in different orders (and E[x^2] - mean^2 amplifies the last bits), agree to 1e-9
@@ -887,6 +893,10 @@ def test_an_utterance_gives_the_same_bits_alone_and_beside_a_long_neighbour(name
         got = run_product_batch(ma, cfg, [b.tobytes() for b in batch], ch, bps)
         assert same(got[0], alone)
         assert same(got[1], alone_mid)
+    tuning(finish=2)  # what a wide batch takes
+    got = run_product_batch(ma, cfg, [b.tobytes() for b in (short, mid, long_)], ch, bps)
+    assert same(got[0], alone)
+    assert same(got[1], alone_mid)
 
 
 @pytest.mark.parametrize("name,frames,force_sweeps", [("c3", 1000, False), ("c3", 1100, False), ("c3", 97, True),
