@@ -220,7 +220,11 @@ int MFCCExtractDevice(MFCCContext *ctx, MFCCPlan *plan, const void *pcmDev, size
 /* Shard plans: z-norm is split so the caller can all-reduce the statistics between the two.
  * MFCCShardColumnSums writes 2*step+1 doubles to sumsDev: sum x, sum x^2 per column over the
  * rank's own rows, then the row count.  MFCCShardNormalize applies (x - mean) / std given the
- * all-reduced vector of the same layout. */
+ * all-reduced vector of the same layout.  Both belong to the plan's latest MFCCExtractDevice call
+ * and take the matrix that call filled: the sums are those of the rows it produced (the
+ * extraction leaves them with the plan as per-segment partial sums, so no second pass over the
+ * matrix is made), and the normalised rows are formed again from the static features the plan
+ * keeps, the matrix being written, not read. */
 int MFCCShardColumnSums(MFCCContext *ctx, MFCCPlan *plan, const void *outDev, double *sumsDev,
                         void *stream);
 int MFCCShardNormalize(MFCCContext *ctx, MFCCPlan *plan, void *outDev, const double *sumsDev,
@@ -260,7 +264,7 @@ int MFCCShardExchange(void *comm, int isInt64, void *valuesDev, int count, void 
 /* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc): the column sums of
  * MFCCShardColumnSums -- sum x, sum x^2 per column, then the row count, 2*step+1 doubles to
- * sumsDev, bit-identical to it -- of a [rows x step] matrix of float (MFCC_PREC_F32) or double in
+ * sumsDev, the same double-precision terms added in a fixed order of its own -- of a [rows x step] matrix of float (MFCC_PREC_F32) or double in
  * device memory, on the current device, without a context or a plan and without any hipMalloc /
  * hipFree.  The per-chunk partial sums go to a 4 MiB device array inside the library (one copy
  * per GPU, held until the process ends): ceil(rows / 256) * 2 * step * 8 bytes must fit, larger

@@ -94,7 +94,7 @@ struct MFCCPlan {
     int32_t *dSegs = nullptr, *dSegBegin = nullptr; // segments {utterance, first row}, first segment of every utterance
     double *dSegPartial = nullptr, *dSegStats = nullptr;
     int numSegs = 0;
-    int strColBlock = 0, strColBlocks = 0, strChunkRows = 0, strWaveElems = 0, strRedOffset = 0;
+    int strColBlock = 0, strColBlocks = 0, strChunkRows = 0, strWaveElems = 0, strRedOffset = 0, strFast = 0, strStage = 0;
     int regRows = kRegRows; // rows per block of the regression / fused delta kernels
     void *dStatics = nullptr; // totalRows x vSize
     int finSubRows = 0, finStaticElems = 0, finRedOffset = 0, finRegRows = 0;
@@ -1082,18 +1082,21 @@ static int finish_plan(MFCCPlan *p)
     // LDS budget (two workgroups per CU) beside the sub-tile buffers.
     p->uttFinish = false;
     p->finStream = false;
-    const bool wantFinish = !p->shard && c->cfg.regreOrder <= 3 && (c->cfg.regreOrder >= 2 || c->cfg.znormFlag) &&
+    const bool wantFinish = c->cfg.regreOrder <= 3 && (c->cfg.regreOrder >= 2 || c->cfg.znormFlag) &&
                             p->totalRows > 0 && !tune.noUttFinish && tune.finish != 3;
     if (wantFinish) {
         const size_t elb = c->cfg.precision == MFCC_PREC_F64 ? 8 : 4;
         int64_t maxFrames = 1;
         for (const UttDesc &d : p->utts) maxFrames = std::max<int64_t>(maxFrames, d.numFrames);
         // Segment-streaming kernels (any utterance length; the partition of an utterance's rows does not
-        // depend on the batch): the default whenever their LDS regions fit.
+        // depend on the batch): the default whenever their LDS regions fit and the window is short.
         size_t strLds = 0;
         const bool strFits = stream_finish_geometry(c->vSize, c->cfg.regreOrder, c->cfg.delwin, (int)elb, tune.streamRows, &p->strColBlock,
-                                                    &p->strColBlocks, &p->strChunkRows, &p->strWaveElems, &p->strRedOffset, &strLds);
-        if (strFits && (tune.finish == 2 || tune.finish == 0)) {
+                                                    &p->strColBlocks, &p->strChunkRows, &p->strWaveElems, &p->strRedOffset, &strLds, &p->strFast, &p->strStage);
+        // (regression windows beyond the register path's -- delwin > 3 -- run faster through the row-block
+        // kernels, or the whole-utterance one where it fits)
+        const bool strGood = p->strFast || c->cfg.regreOrder == 1;
+        if (strFits && (tune.finish == 2 || (tune.finish == 0 && strGood))) {
             p->uttFinish = p->finStream = true;
             p->finLds = strLds;
             const int segRows = stream_finish_seg_chunks() * p->strChunkRows;
@@ -1119,7 +1122,7 @@ static int finish_plan(MFCCPlan *p)
         // Whole-utterance-in-LDS kernel: batch plans whose longest utterance's static rows fit the LDS
         // budget (two workgroups per CU) beside the sub-tile buffers.
         const size_t statics = (size_t)maxFrames * c->vSize;
-        for (int sr = 64; sr >= 8 && !p->uttFinish && c->vSize <= kBlock; sr /= 2) {
+        for (int sr = 64; sr >= 8 && !p->uttFinish && !p->shard && c->vSize <= kBlock; sr /= 2) {
             const size_t elems = statics + (size_t)(sr + 2 * c->cfg.delwin) * c->vSize + (size_t)sr * c->step;
             const size_t redOff = (elems * elb + 15) & ~(size_t)15;
             const size_t total = redOff + (2 * (size_t)kFinishBlock + 2 * (size_t)c->step) * sizeof(double);
@@ -1569,8 +1572,9 @@ static int run_delta(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
     return MFCC_OK;
 }
 
+// phase (segment-streaming kernels): 0 batch plan; 1 shard plan's extraction; 2 shard plan's normalisation
 template <typename T>
-static int run_finish(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
+static int run_finish(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream, int phase = 0)
 {
     double sigmaT2 = 0.0;
     for (int t = 1; t <= c->cfg.delwin; ++t) sigmaT2 += (double)t * t;
@@ -1596,6 +1600,7 @@ static int run_finish(MFCCContext *c, MFCCPlan *p, void *outDev, void *stream)
         sa.vSize = a.vSize, sa.step = a.step, sa.delwin = a.delwin, sa.znorm = a.znorm;
         sa.colBlock = p->strColBlock, sa.numColBlocks = p->strColBlocks, sa.chunkRows = p->strChunkRows;
         sa.waveElems = p->strWaveElems, sa.redOffset = p->strRedOffset, sa.sigmaT2 = a.sigmaT2;
+        sa.fastPath = p->strFast, sa.stageOut = p->strStage, sa.phase = phase;
         sa.partial = p->dSegPartial, sa.stats = p->dSegStats;
         const int rc = launch_seg_finish(c->cfg.precision, &sa, c->cfg.regreOrder, p->finLds, stream);
         if (rc) return set_error("segment finishing kernel launch failed (HIP error %d)", rc), MFCC_E_DEVICE;
@@ -1689,7 +1694,10 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
         const int e = launch_energy_norm(c->cfg.precision, frontOut, p->dUtts, p->numUtts, frontStep, c->M, 50.0, 0.1, stream);
         if (e) return set_error("energy normalisation kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
     }
-    if (p->uttFinish) return f64 ? run_finish<double>(c, p, outDev, stream) : run_finish<float>(c, p, outDev, stream);
+    if (p->uttFinish) {
+        const int phase = p->shard ? 1 : 0;
+        return f64 ? run_finish<double>(c, p, outDev, stream, phase) : run_finish<float>(c, p, outDev, stream, phase);
+    }
     const bool fused = p->deltaSubRows > 0;
     if (fused)
         rc = f64 ? run_delta<double>(c, p, outDev, stream) : run_delta<float>(c, p, outDev, stream);
@@ -1714,6 +1722,16 @@ extern "C" int MFCCShardColumnSums(MFCCContext *c, MFCCPlan *p, const void *outD
     if (!c || !p || p->ctx != c || !p->shard || !sumsDev) return set_error("bad argument"), MFCC_E_ARG;
     if (!c->cfg.znormFlag) return set_error("znormFlag is off"), MFCC_E_CONFIG;
     DEVICE_SCOPE(c->device);
+    if (p->finStream) {
+        // the segments' sums are what the plan's last MFCCExtractDevice left beside the rows
+        if (p->numSegs == 0) {
+            HIP_TRY(hipMemsetAsync(sumsDev, 0, (size_t)(2 * c->step + 1) * sizeof(double), static_cast<hipStream_t>(stream)));
+            return MFCC_OK;
+        }
+        const int e = launch_seg_shard_sums(p->dSegPartial, p->dUtts, p->numSegs, sumsDev, c->step, stream);
+        if (e) return set_error("shard statistics kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
+        return MFCC_OK;
+    }
     if (p->numChunks == 0) {
         HIP_TRY(hipMemsetAsync(sumsDev, 0, (size_t)(2 * c->step + 1) * sizeof(double), static_cast<hipStream_t>(stream)));
         return MFCC_OK;
@@ -1731,6 +1749,16 @@ extern "C" int MFCCShardNormalize(MFCCContext *c, MFCCPlan *p, void *outDev, con
                                   void *stream)
 {
     if (!c || !p || p->ctx != c || !p->shard || !sumsDev) return set_error("bad argument"), MFCC_E_ARG;
+    if (p->finStream) {
+        // the rows are formed again from the plan's static features and leave normalised: the
+        // matrix is written, not read
+        if (p->numSegs == 0) return MFCC_OK;
+        if (!outDev) return set_error("NULL device buffer"), MFCC_E_ARG;
+        DEVICE_SCOPE(c->device);
+        const int e = launch_totals_to_stats(sumsDev, p->dSegStats, c->step, stream);
+        if (e) return set_error("statistics kernel launch failed (HIP error %d)", e), MFCC_E_DEVICE;
+        return c->cfg.precision == MFCC_PREC_F64 ? run_finish<double>(c, p, outDev, stream, 2) : run_finish<float>(c, p, outDev, stream, 2);
+    }
     if (p->numChunks == 0) return MFCC_OK;
     if (!outDev) return set_error("NULL device buffer"), MFCC_E_ARG;
     DEVICE_SCOPE(c->device);

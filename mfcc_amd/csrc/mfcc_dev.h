@@ -154,14 +154,20 @@ struct StreamArgs {
     int chunkRows;          // rows a wave finishes per chunk (a segment: stream_finish_seg_chunks() chunks)
     int waveElems;          // LDS elements of one wave's region
     int redOffset;          // byte offset of the reduction scratch in LDS
+    int fastPath;           // chunks of kFastRows rows per lane, delwin 1 .. 3: interior chunks form their deltas in registers
+    int stageOut;           // ... and their finished rows leave through LDS as one contiguous piece
+    int phase;              // 0: batch plan (sums, statistics, rows); 1: shard plan's extraction (rows as they are + sums);
+                            // 2: shard plan's normalisation (rows again, normalised with `stats`)
     double sigmaT2;
     double *partial;        // numSegs x 2*step: column sums and sums of squares of every segment
     double *stats;          // numUtts x 2*step: mean | 1 / std
 };
 int stream_finish_seg_chunks();
 bool stream_finish_geometry(int vSize, int orders, int delwin, int elemBytes, int wantRows, int *colBlock, int *numColBlocks,
-                            int *chunkRows, int *waveElems, int *redOffset, size_t *ldsBytes);
+                            int *chunkRows, int *waveElems, int *redOffset, size_t *ldsBytes, int *fastPath, int *stageOut);
 int launch_seg_finish(int precision, const void *args, int orders, size_t ldsBytes, void *stream);
+int launch_seg_shard_sums(const double *partial, const UttDesc *utts, int numSegs, double *sums, int step, void *stream);
+int launch_totals_to_stats(const double *totals, double *stats, int step, void *stream);
 
 template <typename T>
 struct StatArgs {

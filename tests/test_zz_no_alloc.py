@@ -1,7 +1,9 @@
 """GPU test of MFCCColumnSumsNoAlloc, the entry point for callers that cannot allocate device
 memory: through the C ABI, against MFCCShardColumnSums (the entry point it is a variant of) on the
-same matrix, bit for bit, on two calls in a row, the second with a smaller input; plus the refusal
-of matrices whose partial sums do not fit the fixed scratch array."""
+same matrix, on two calls in a row, the second with a smaller input; plus the refusal of matrices
+whose partial sums do not fit the fixed scratch array.  Both add the same double-precision terms,
+in different fixed orders (row chunks of 256 here, the plan's segments there): the row count must
+be equal, every sum must agree to 1e-12 of the sum of its terms' magnitudes."""
 import ctypes as C
 
 import numpy as np
@@ -47,7 +49,11 @@ def test_no_alloc_column_sums_match_the_plan_entry_point(precision):
         torch.cuda.synchronize()
         w, g = want.cpu().numpy(), got.cpu().numpy()
         assert g[-1] == out.shape[0] == w[-1]
-        assert np.array_equal(g.view(np.uint64), w.view(np.uint64))  # bit for bit (NaN columns included)
+        x = out.double().cpu().numpy()
+        mag = np.concatenate([np.abs(x).sum(axis=0), (x * x).sum(axis=0), [0.0]])
+        assert np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(np.isinf(g), np.isinf(w))
+        fin = np.isfinite(w)
+        assert np.all(np.abs(g - w)[fin] <= 1e-12 * mag[fin])
 
 
 def test_no_alloc_column_sums_edges():
