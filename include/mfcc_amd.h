@@ -220,11 +220,13 @@ int MFCCExtractDevice(MFCCContext *ctx, MFCCPlan *plan, const void *pcmDev, size
 /* Shard plans: z-norm is split so the caller can all-reduce the statistics between the two.
  * MFCCShardColumnSums writes 2*step+1 doubles to sumsDev: sum x, sum x^2 per column over the
  * rank's own rows, then the row count.  MFCCShardNormalize applies (x - mean) / std given the
- * all-reduced vector of the same layout.  Both belong to the plan's latest MFCCExtractDevice call
- * and take the matrix that call filled: the sums are those of the rows it produced (the
- * extraction leaves them with the plan as per-segment partial sums, so no second pass over the
- * matrix is made), and the normalised rows are formed again from the static features the plan
- * keeps, the matrix being written, not read. */
+ * all-reduced vector of the same layout.  Both belong to the plan's latest MFCCExtractDevice call.
+ * With znormFlag a shard plan's MFCCExtractDevice need not fill outDev: it keeps the static features
+ * with the plan and leaves the sums of the rows they give as per-segment partial sums there;
+ * MFCCShardColumnSums adds those up (outDev is not read), and MFCCShardNormalize forms the rows
+ * from the kept static features and writes them normalised (outDev is written, not read): the
+ * matrix travels to memory once.  Without znormFlag MFCCExtractDevice fills outDev as for a batch
+ * plan. */
 int MFCCShardColumnSums(MFCCContext *ctx, MFCCPlan *plan, const void *outDev, double *sumsDev,
                         void *stream);
 int MFCCShardNormalize(MFCCContext *ctx, MFCCPlan *plan, void *outDev, const double *sumsDev,

@@ -154,10 +154,10 @@ struct StreamArgs {
     int chunkRows;          // rows a wave finishes per chunk (a segment: stream_finish_seg_chunks() chunks)
     int waveElems;          // LDS elements of one wave's region
     int redOffset;          // byte offset of the reduction scratch in LDS
-    int fastPath;           // chunks of kFastRows rows per lane, delwin 1 .. 3: interior chunks form their deltas in registers
-    int stageOut;           // ... and their finished rows leave through LDS as one contiguous piece
-    int phase;              // 0: batch plan (sums, statistics, rows); 1: shard plan's extraction (rows as they are + sums);
-                            // 2: shard plan's normalisation (rows again, normalised with `stats`)
+    int fastPath;           // register path: delwin is one of its compile-time values, a chunk is reg_rows(delwin) rows per lane
+    int stageOut;           // ... and finished rows leave through LDS as one contiguous piece
+    int phase;              // 0: batch plan (sums, statistics, rows); 1: shard plan's extraction (the segments' sums when a
+                            // z-norm follows, else the rows); 2: shard plan's normalisation (the rows, normalised with `stats`)
     double sigmaT2;
     double *partial;        // numSegs x 2*step: column sums and sums of squares of every segment
     double *stats;          // numUtts x 2*step: mean | 1 / std

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "front_util.h"
 #include "mfcc_host.h"
@@ -41,22 +42,60 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kFastRows = 8; // rows per lane of a chunk on the register path
+// Rows per lane of a chunk on the register path: a lane reads rows + 2 halo values of its column
+// and forms rows + 2 delwin first deltas from them, so longer windows take more rows at a time.
+__host__ __device__ constexpr int reg_rows(int dw) { return dw <= 3 ? 8 : 16; }
+
+template <typename T>
+struct SegCommon {
+    // The delta's quotient sum / sigmaT2, correctly rounded as the other delta kernels form it.  In
+    // single precision: the double product with 1 / sigmaT2, rounded to single.  (sigmaT2 is an
+    // integer below 1000 and sum has 24 significant bits, so the exact quotient stays 2^-26 / sigmaT2
+    // > 1e-11 (relative) away from every rounding boundary of single precision, a thousand times
+    // the error of that product: both round to the same number.)
+    double sigmaT2, rsigma;
+    __device__ __forceinline__ T quotient(T sum) const
+    {
+        if constexpr (sizeof(T) == 4)
+            return (T)((double)sum * rsigma);
+        else
+            return (T)((double)sum / sigmaT2);
+    }
+};
+
+// The segment's column sums: over the waves and their row lanes, in a fixed order.
+template <int ORD>
+__device__ __forceinline__ void seg_reduce(const double (&s1)[ORD], const double (&s2)[ORD], double *red, double *part, bool live, int tid,
+                                           int CB, int colBlock, int rowLanes, int W, int step)
+{
+#pragma unroll
+    for (int o = 0; o < ORD; ++o) {
+        red[tid] = live ? s1[o] : 0.0;
+        red[kSegWaves * 64 + tid] = live ? s2[o] : 0.0;
+        __syncthreads();
+        if (tid < CB) {
+            double t1 = 0, t2 = 0;
+            for (int w = 0; w < kSegWaves; ++w)
+                for (int q = 0; q < rowLanes; ++q) {
+                    t1 += red[w * 64 + q * colBlock + tid];
+                    t2 += red[kSegWaves * 64 + w * 64 + q * colBlock + tid];
+                }
+            part[o * W + tid] = t1;
+            part[step + o * W + tid] = t2;
+        }
+        __syncthreads();
+    }
+}
 
 // MODE 0: column sums of the segment (over the rows the plan owns: all of them in a batch plan, a
-// shard plan's without its halo frames); 1: finished rows of the segment, normalised when a.znorm;
-// 2: finished rows as they are and their column sums in one sweep (what a shard plan's extraction
-// leaves: the totals come from every shard, the normalisation is a later call).
-// DW > 0: delwin = DW is known at compile time and a chunk is kFastRows rows per lane; chunks that
-// lie inside the utterance with their halo rows (no clamped row) then take the register path: the
-// chunk's statics sit in LDS column by column, a lane reads the kFastRows + 2 halo consecutive rows
-// of its column once and forms every delta in registers.  Same arithmetic, same results.
-template <typename T, int ORD, int DW, int MODE>
+// shard plan's without its halo frames); 1: finished rows of the segment, normalised when a.znorm.
+// Any delwin (read from the arguments): statics and first deltas of a chunk go through LDS.
+template <typename T, int ORD, int MODE>
 __global__ __launch_bounds__(kSegWaves * 64) void k_seg_pass(const StreamArgs<T> a)
 {
-    constexpr bool WRITE = MODE >= 1, SUMS = MODE != 1;
+    constexpr bool WRITE = MODE == 1, SUMS = MODE == 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
-    const int W = a.vSize, dw = DW > 0 ? DW : a.delwin, step = a.step, RW = a.chunkRows;
+    const int W = a.vSize, dw = a.delwin, step = a.step, RW = a.chunkRows;
     const int2 sg = reinterpret_cast<const int2 *>(a.segs)[blockIdx.x]; // utterance, first row of the segment
     const UttDesc ud = a.utts[sg.x];
     const int n = ud.numFrames;
@@ -72,30 +111,18 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_pass(const StreamArgs<T>
     // LDS: per wave [statics (RW + 2 h) x colBlock | first deltas (RW + 2 h1) x colBlock], then the
     // reduction scratch (2 x 256 doubles)
     T *S = reinterpret_cast<T *>(ssm) + (size_t)wave * a.waveElems;
-    T *D1 = S + (((size_t)(RW + 2 * h) * a.colBlock + a.colBlock + 3) & ~(size_t)3); // (the register path's statics: colBlock x (RW + 2 h + 1))
-    T *stage = D1;                                               // register path: RW finished rows (stageOut)
+    T *D1 = S + (size_t)(RW + 2 * h) * a.colBlock;
     double *red = reinterpret_cast<double *>(ssm + a.redOffset);
 
     const T *src = a.statics + ud.outRow * W + c0;
     T *dst = a.out + ud.outRow * step + c0;
-    // The delta's quotient sum / sigmaT2, correctly rounded as the other delta kernels form it.  In
-    // single precision: the double product with 1 / sigmaT2, rounded to single.  (sigmaT2 is an
-    // integer below 1000 and sum has 24 significant bits, so the exact quotient stays 2^-26 / sigmaT2
-    // > 1e-11 (relative) away from every rounding boundary of single precision, a thousand times
-    // the error of that product: both round to the same number.)
-    const double rsigma = 1.0 / a.sigmaT2;
-    auto quotient = [&](T sum) -> T {
-        if constexpr (sizeof(T) == 4)
-            return (T)((double)sum * rsigma);
-        else
-            return (T)((double)sum / a.sigmaT2);
-    };
+    const SegCommon<T> cm = {a.sigmaT2, 1.0 / a.sigmaT2};
     const int segEnd = min(n, sg.y + kSegChunks * RW);
 
     double mean[ORD], rstd[ORD];
 #pragma unroll
     for (int o = 0; o < ORD; ++o) mean[o] = 0.0, rstd[o] = 1.0;
-    if (MODE == 1 && a.znorm && live) {
+    if (WRITE && a.znorm && live) {
         const double *st = a.stats + (size_t)sg.x * 2 * step + c0 + col;
 #pragma unroll
         for (int o = 0; o < ORD; ++o) {
@@ -106,121 +133,10 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_pass(const StreamArgs<T>
     double s1[ORD], s2[ORD];
 #pragma unroll
     for (int o = 0; o < ORD; ++o) s1[o] = s2[o] = 0;
-
-    // what a row's values go through once they are formed
     const int ownLo = ud.ownBegin, ownHi = ud.ownBegin + ud.ownCount;
-    auto consume = [&](const T (&x)[ORD], T *orow, int row) {
-        if constexpr (SUMS) {
-            const bool own = row >= ownLo && row < ownHi;
-#pragma unroll
-            for (int o = 0; o < ORD; ++o) {
-                const double xd = own ? (double)x[o] : 0.0;
-                s1[o] += xd;
-                s2[o] += xd * xd;
-            }
-        }
-        if constexpr (WRITE) {
-#pragma unroll
-            for (int o = 0; o < ORD; ++o) {
-                T v = x[o];
-                if (MODE == 1 && a.znorm) v = (T)(((double)v - mean[o]) * rstd[o]);
-                orow[o * W] = v;
-            }
-        }
-    };
-
-    // register path: the rows of a chunk on their way from memory (row rl + i rowLanes in pf[i])
-    constexpr int NPF = DW > 0 ? kFastRows + 2 * (ORD - 1) * DW : 1;
-    T pf[NPF];
-    bool havePf = false;
-    auto interior = [&](int s0) { return s0 - h >= 0 && s0 + RW + h <= n; };
-    auto fetch = [&](int s0) {
-        if (live) {
-            const T *g = src + (long long)(s0 - h) * W + col;
-#pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                const int p = rl + i * rowLanes;
-                if (p < RW + 2 * h) pf[i] = g[(long long)p * W];
-            }
-        }
-    };
-    // 16-byte vectors of the staged rows: VEC elements; `head` single elements lie before the first
-    // aligned output element of a chunk (the same for every chunk: a chunk is a multiple of 8 rows)
-    constexpr int VEC = 16 / (int)sizeof(T);
-    typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    const int mis = (int)((ud.outRow * step + c0) % VEC);
-    const int head = (VEC - mis) % VEC;
-    T *stageP = stage + mis;
 
     for (int s = sg.y + wave * RW; s < segEnd; s += kSegWaves * RW) {
         const int rows = min(RW, n - s);
-        if constexpr (DW > 0 && ORD >= 2) {
-            if (interior(s)) { // (wave-uniform) no row of the chunk or its halo is clamped
-                constexpr int K = kFastRows, HH = (ORD - 1) * DW, HH1 = ORD == 3 ? DW : 0;
-                const int pitch = RW + 2 * HH + 1; // (odd pitches spread the columns over the banks)
-                if (!havePf) fetch(s);
-                if (live) {
-#pragma unroll
-                    for (int i = 0; i < NPF; ++i) {
-                        const int p = rl + i * rowLanes;
-                        if (p < RW + 2 * HH) S[col * pitch + p] = pf[i];
-                    }
-                }
-                wave_sync_lds();
-                // the next chunk's rows travel while this one is worked on
-                const int sNext = s + kSegWaves * RW;
-                havePf = sNext < segEnd && interior(sNext);
-                if (havePf) fetch(sNext);
-                if (live) {
-                    const T *q = S + col * pitch + rl * K; // the lane's rows: rl K .. rl K + K - 1 of the chunk
-                    T sv[K + 2 * HH];
-#pragma unroll
-                    for (int i = 0; i < K + 2 * HH; ++i) sv[i] = q[i];
-                    T dv[K + 2 * HH1]; // first deltas of rows -HH1 .. K + HH1 - 1 of the lane's
-#pragma unroll
-                    for (int m = 0; m < K + 2 * HH1; ++m) {
-                        T sum = 0;
-#pragma unroll
-                        for (int tau = 1; tau <= DW; ++tau) sum = fma_t((T)tau, sv[HH - HH1 + m + tau] - sv[HH - HH1 + m - tau], sum);
-                        dv[m] = quotient(sum);
-                    }
-                    T *orow = WRITE ? (a.stageOut ? stageP + (rl * K) * step + col : dst + (long long)(s + rl * K) * step + col) : nullptr;
-#pragma unroll
-                    for (int r = 0; r < K; ++r) {
-                        T x[ORD];
-                        x[0] = sv[HH + r];
-                        x[1] = dv[HH1 + r];
-                        if constexpr (ORD >= 3) {
-                            T sum = 0;
-#pragma unroll
-                            for (int tau = 1; tau <= DW; ++tau) sum = fma_t((T)tau, dv[HH1 + r + tau] - dv[HH1 + r - tau], sum);
-                            x[2] = quotient(sum);
-                        }
-                        consume(x, WRITE ? orow + (long long)r * step : nullptr, s + rl * K + r);
-                    }
-                }
-                if constexpr (WRITE) {
-                    if (a.stageOut) {
-                        // The chunk's RW finished rows are one contiguous piece of the output.  The staging
-                        // area is shifted so that an element is 16-byte aligned there exactly when it is
-                        // in the output: a few single elements up to the first aligned one, 16-byte
-                        // vectors, single elements again.
-                        wave_sync_lds();
-                        T *o = dst + (long long)s * step;
-                        const int total = RW * step;
-                        const int nvec = (total - head) / VEC;
-                        if (lane < head) o[lane] = stageP[lane];
-                        for (int v = lane; v < nvec; v += 64)
-                            *reinterpret_cast<vec_t *>(o + head + VEC * v) = *reinterpret_cast<const vec_t *>(stageP + head + VEC * v);
-                        const int done = head + VEC * nvec;
-                        if (lane < total - done) o[done + lane] = stageP[done + lane];
-                    }
-                }
-                wave_sync_lds();
-                continue;
-            }
-            havePf = false;
-        }
         if (live) {
             // static rows s - h .. s + rows + h - 1, each at its clamped row
             for (int p = rl; p < rows + 2 * h; p += rowLanes) {
@@ -239,7 +155,7 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_pass(const StreamArgs<T>
                     const T *q = S + (t - (s - h)) * CB + col;
                     T sum = 0;
                     for (int tau = 1; tau <= dw; ++tau) sum = fma_t((T)tau, q[tau * CB] - q[-tau * CB], sum);
-                    D1[p * CB + col] = quotient(sum);
+                    D1[p * CB + col] = cm.quotient(sum);
                 }
             }
             wave_sync_lds();
@@ -253,34 +169,262 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_pass(const StreamArgs<T>
                     const T *q = D1 + (r + h1) * CB + col;
                     T sum = 0;
                     for (int tau = 1; tau <= dw; ++tau) sum = fma_t((T)tau, q[tau * CB] - q[-tau * CB], sum);
-                    x[2] = quotient(sum);
+                    x[2] = cm.quotient(sum);
                 }
-                consume(x, WRITE ? dst + (long long)(s + r) * step + col : nullptr, s + r);
+                if constexpr (SUMS) {
+                    const bool own = s + r >= ownLo && s + r < ownHi;
+#pragma unroll
+                    for (int o = 0; o < ORD; ++o) {
+                        const double xd = own ? (double)x[o] : 0.0;
+                        s1[o] += xd;
+                        s2[o] += xd * xd;
+                    }
+                } else {
+                    T *orow = dst + (long long)(s + r) * step + col;
+#pragma unroll
+                    for (int o = 0; o < ORD; ++o) {
+                        T v = x[o];
+                        if (a.znorm) v = (T)(((double)v - mean[o]) * rstd[o]);
+                        orow[o * W] = v;
+                    }
+                }
             }
         }
         wave_sync_lds(); // the chunk's rows are consumed before the next chunk overwrites them
     }
-    if constexpr (SUMS) {
-        // the segment's column sums: over the waves and their row lanes, in a fixed order
-        double *part = a.partial + (size_t)blockIdx.x * 2 * step + c0;
+    if constexpr (SUMS)
+        seg_reduce<ORD>(s1, s2, red, a.partial + (size_t)blockIdx.x * 2 * step + c0, live, tid, CB, a.colBlock, rowLanes, W, step);
+}
+
+// The same with delwin = DW known at compile time: a lane owns reg_rows(DW) consecutive rows of its
+// column per chunk, reads them with their halo once -- straight from memory when a column block
+// fills the wave (one row lane: a wave's load is one contiguous row piece), else from the chunk's
+// statics staged in LDS column by column, the next chunk's rows in flight meanwhile -- and forms
+// every delta in registers.  Rows are read at their clamped indices; in a chunk that touches an end
+// of the utterance the first deltas of rows outside it are replaced by the end row's, which is what
+// Regress's clamped pointers give.  Finished rows of a narrow matrix (one column block) leave
+// through LDS as one contiguous piece written in aligned 16-byte vectors.  Same arithmetic, same
+// results as k_seg_pass.
+template <typename T, int ORD, int DW, int MODE, bool DIRECT>
+__global__ __launch_bounds__(kSegWaves * 64) void k_seg_reg(const StreamArgs<T> a)
+{
+    constexpr bool WRITE = MODE == 1, SUMS = MODE == 0;
+    constexpr int K = reg_rows(DW), HH = (ORD - 1) * DW, HH1 = ORD == 3 ? DW : 0;
+    constexpr int NS = K + 2 * HH, ND = K + 2 * HH1;
+    constexpr bool PREFETCH = !DIRECT && NS <= 24; // the staged form keeps the next chunk's rows in registers
+    extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
+    const int W = a.vSize, step = a.step, RW = a.chunkRows;
+    const int2 sg = reinterpret_cast<const int2 *>(a.segs)[blockIdx.x];
+    const UttDesc ud = a.utts[sg.x];
+    const int n = ud.numFrames;
+    // The straight-from-memory form writes every column block of its rows itself, one after the
+    // other (the pieces of an output row then reach the cache together and leave it as whole lines);
+    // otherwise a workgroup has one column block (blockIdx.y).
+    constexpr bool ALLBLOCKS = DIRECT && WRITE;
+    const int cbBegin = ALLBLOCKS ? 0 : (int)blockIdx.y, cbEnd = ALLBLOCKS ? a.numColBlocks : (int)blockIdx.y + 1;
+    int c0 = cbBegin * a.colBlock;
+    int CB = min(a.colBlock, W - c0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int rowLanes = 64 / a.colBlock;
+    const int col = lane % a.colBlock, rl = lane / a.colBlock;
+    bool live = rl < rowLanes && col < CB;
+    constexpr bool direct = DIRECT; // (one row lane: rowLanes == 1)
+
+    // LDS (staged form): per wave [statics colBlock x (RW + 2 HH + 1) | RW finished rows], then the
+    // reduction scratch
+    T *S = reinterpret_cast<T *>(ssm) + (size_t)wave * a.waveElems;
+    T *stage = S + (direct ? 0 : (((size_t)(RW + 2 * HH + 1) * a.colBlock + 3) & ~(size_t)3));
+    double *red = reinterpret_cast<double *>(ssm + a.redOffset);
+    const int pitch = RW + 2 * HH + 1; // (odd pitches spread the columns over the banks)
+
+    const T *src = a.statics + ud.outRow * W + c0;
+    T *dst = a.out + ud.outRow * step + c0; // (of the current column block)
+    const SegCommon<T> cm = {a.sigmaT2, 1.0 / a.sigmaT2};
+    const int segEnd = min(n, sg.y + kSegChunks * RW);
+
+    double mean[ORD], rstd[ORD];
 #pragma unroll
-        for (int o = 0; o < ORD; ++o) {
-            red[tid] = live ? s1[o] : 0.0;
-            red[kSegWaves * 64 + tid] = live ? s2[o] : 0.0;
-            __syncthreads();
-            if (tid < CB) {
-                double t1 = 0, t2 = 0;
-                for (int w = 0; w < kSegWaves; ++w)
-                    for (int q = 0; q < rowLanes; ++q) {
-                        t1 += red[w * 64 + q * a.colBlock + tid];
-                        t2 += red[kSegWaves * 64 + w * 64 + q * a.colBlock + tid];
-                    }
-                part[o * W + tid] = t1;
-                part[step + o * W + tid] = t2;
+    for (int o = 0; o < ORD; ++o) mean[o] = 0.0, rstd[o] = 1.0;
+    auto load_stats = [&]() {
+        if (WRITE && a.znorm && live) {
+            const double *st = a.stats + (size_t)sg.x * 2 * step + c0 + col;
+#pragma unroll
+            for (int o = 0; o < ORD; ++o) {
+                mean[o] = st[o * W];
+                rstd[o] = st[step + o * W];
             }
-            __syncthreads();
         }
+    };
+    load_stats();
+    double s1[ORD], s2[ORD];
+#pragma unroll
+    for (int o = 0; o < ORD; ++o) s1[o] = s2[o] = 0;
+    const int ownLo = ud.ownBegin, ownHi = ud.ownBegin + ud.ownCount;
+
+    // rows are addressed from the segment's first halo row (a uniform base and a 32-bit offset per lane)
+    const int segRow0 = sg.y - HH;
+    const T *segBase = src + (long long)segRow0 * W; // (of the current column block)
+    const T *segBase0 = segBase - c0;
+    T *dst0 = dst - c0;
+    // staged form: the rows of a chunk on their way from memory (row rl + i rowLanes of it in pf[i])
+    constexpr int NPF = PREFETCH ? NS : 1;
+    T pf[NPF];
+    bool havePf = false;
+    auto fetch = [&](int s0) {
+        if (live) {
+            if (s0 - HH >= 0 && s0 + RW + HH <= n) { // (wave-uniform) no row is clamped: one base, constant strides
+                const T *g = segBase + (unsigned)((s0 - HH - segRow0 + rl) * W + col);
+#pragma unroll
+                for (int i = 0; i < NPF; ++i)
+                    if (rl + i * rowLanes < RW + 2 * HH) pf[i] = g[(unsigned)(i * rowLanes * W)];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    const int p = rl + i * rowLanes;
+                    if (p < RW + 2 * HH) pf[i] = segBase[(unsigned)((min(max(s0 - HH + p, 0), n - 1) - segRow0) * W + col)];
+                }
+            }
+        }
+    };
+    // 16-byte vectors of the staged rows: VEC elements; `head` single elements lie before the first
+    // aligned output element of a chunk (the same for every chunk: a chunk is a multiple of 8 rows)
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int mis = (int)((ud.outRow * step + c0) % VEC);
+    const int head = (VEC - mis) % VEC;
+    T *stageP = stage + mis;
+
+    for (int s = sg.y + wave * RW; s < segEnd; s += kSegWaves * RW) {
+      for (int cbk = cbBegin; cbk < cbEnd; ++cbk) {
+        if constexpr (ALLBLOCKS) {
+            if (a.numColBlocks > 1) {
+                c0 = cbk * a.colBlock;
+                CB = min(a.colBlock, W - c0);
+                live = col < CB;
+                segBase = segBase0 + c0;
+                dst = dst0 + c0;
+                load_stats();
+            }
+        }
+        const int rows = min(RW, n - s);
+        const int r0 = s + rl * K; // the lane's first row
+        T sv[NS];                  // statics of rows r0 - HH .. r0 + K + HH - 1, each at its clamped row
+        if constexpr (DIRECT) {
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) sv[i] = segBase[(unsigned)((min(max(r0 - HH + i, 0), n - 1) - segRow0) * W + col)];
+            }
+        } else {
+            if constexpr (PREFETCH) {
+                if (!havePf) fetch(s);
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) {
+                        const int p = rl + i * rowLanes;
+                        if (p < RW + 2 * HH) S[col * pitch + p] = pf[i];
+                    }
+                }
+            } else {
+                if (live)
+                    for (int p = rl; p < RW + 2 * HH; p += rowLanes)
+                        S[col * pitch + p] = segBase[(unsigned)((min(max(s - HH + p, 0), n - 1) - segRow0) * W + col)];
+            }
+            wave_sync_lds();
+            if constexpr (PREFETCH) {
+                // the next chunk's rows travel while this one is worked on
+                const int sNext = s + kSegWaves * RW;
+                havePf = sNext < segEnd;
+                if (havePf) fetch(sNext);
+            }
+            if (live) {
+                const T *q = S + col * pitch + rl * K;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) sv[i] = q[i];
+            }
+        }
+        if (live) {
+            T dv[ND > 0 ? ND : 1]; // first deltas of rows r0 - HH1 .. r0 + K + HH1 - 1
+            if constexpr (ORD >= 2) {
+#pragma unroll
+                for (int m = 0; m < ND; ++m) {
+                    T sum = 0;
+#pragma unroll
+                    for (int tau = 1; tau <= DW; ++tau) sum = fma_t((T)tau, sv[HH - HH1 + m + tau] - sv[HH - HH1 + m - tau], sum);
+                    dv[m] = cm.quotient(sum);
+                }
+                if constexpr (ORD >= 3) {
+                    if (s - HH < 0 || s + RW + HH > n) { // (wave-uniform) the chunk touches an end of the utterance
+                        const int m0 = HH1 - r0, m1 = n - 1 - r0 + HH1; // where rows 0 and n - 1 sit in dv
+                        T dLo = dv[0], dHi = dv[ND - 1];
+#pragma unroll
+                        for (int m = 0; m < ND; ++m) {
+                            dLo = m == m0 ? dv[m] : dLo;
+                            dHi = m == m1 ? dv[m] : dHi;
+                        }
+#pragma unroll
+                        for (int m = 0; m < ND; ++m) dv[m] = m < m0 ? dLo : (m > m1 ? dHi : dv[m]);
+                    }
+                }
+            }
+            T *orow = WRITE ? (a.stageOut ? stageP + (rl * K) * step + col : dst + (long long)r0 * step + col) : nullptr;
+            // (ALL: every row of the chunk is one the plan owns and lies inside the utterance -- no per-row test)
+            auto rows_out = [&](auto allTag) {
+                constexpr bool ALL = decltype(allTag)::value;
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    T x[ORD];
+                    x[0] = sv[HH + r];
+                    if constexpr (ORD >= 2) x[1] = dv[HH1 + r];
+                    if constexpr (ORD >= 3) {
+                        T sum = 0;
+#pragma unroll
+                        for (int tau = 1; tau <= DW; ++tau) sum = fma_t((T)tau, dv[HH1 + r + tau] - dv[HH1 + r - tau], sum);
+                        x[2] = cm.quotient(sum);
+                    }
+                    if constexpr (SUMS) {
+                        const bool own = ALL || (r0 + r >= ownLo && r0 + r < ownHi);
+#pragma unroll
+                        for (int o = 0; o < ORD; ++o) {
+                            const double xd = own ? (double)x[o] : 0.0;
+                            s1[o] += xd;
+                            s2[o] += xd * xd;
+                        }
+                    } else {
+                        if (ALL || a.stageOut || r0 + r < n) { // (staged rows past the last one are not copied out)
+#pragma unroll
+                            for (int o = 0; o < ORD; ++o) {
+                                T v = x[o];
+                                if (a.znorm) v = (T)(((double)v - mean[o]) * rstd[o]);
+                                orow[(long long)r * step + o * W] = v;
+                            }
+                        }
+                    }
+                }
+            };
+            rows_out(std::false_type{}); // (one copy of the unrolled rows: two made the long-window kernels outgrow the instruction cache)
+        }
+        if constexpr (WRITE) {
+            if (a.stageOut) {
+                // The chunk's finished rows are one contiguous piece of the output.  The staging area is
+                // shifted so that an element is 16-byte aligned there exactly when it is in the
+                // output: a few single elements up to the first aligned one, 16-byte vectors,
+                // single elements again.
+                wave_sync_lds();
+                T *o = dst + (long long)s * step;
+                const int total = rows * step;
+                const int nvec = total > head ? (total - head) / VEC : 0;
+                if (lane < min(head, total)) o[lane] = stageP[lane];
+                for (int v = lane; v < nvec; v += 64)
+                    *reinterpret_cast<vec_t *>(o + head + VEC * v) = *reinterpret_cast<const vec_t *>(stageP + head + VEC * v);
+                const int done = min(head, total) + VEC * nvec;
+                if (lane < total - done) o[done + lane] = stageP[done + lane];
+            }
+        }
+        if (!direct) wave_sync_lds(); // the chunk's rows are consumed before the next chunk overwrites them
+      }
     }
+    if constexpr (SUMS)
+        seg_reduce<ORD>(s1, s2, red, a.partial + (size_t)blockIdx.x * 2 * step + c0, live, tid, CB, a.colBlock, rowLanes, W, step);
 }
 
 // Per utterance and value (2 x step of them: sums, then sums of squares): the segments' partials
@@ -320,20 +464,21 @@ __global__ __launch_bounds__(kStatVals *kStatLanes) void k_seg_stats(const doubl
 
 // A shard plan's sums (its one buffer's segments): the same fixed-order addition, the raw sums and
 // the number of owned rows behind them (2 step + 1 doubles, the layout the shards exchange).
-__global__ __launch_bounds__(kStatVals *kStatLanes) void k_seg_shard_sums(const double *partial, const UttDesc *utts, int numSegs,
-                                                                           double *sums, int step)
+constexpr int kShardLanes = 64; // lanes per value: lane j adds segments j, j + 64, ... in order, then the lanes in lane order
+__global__ __launch_bounds__(kStatVals *kShardLanes) void k_seg_shard_sums(const double *partial, const UttDesc *utts, int numSegs,
+                                                                            double *sums, int step)
 {
-    __shared__ double red[kStatLanes][kStatVals];
+    __shared__ double red[kShardLanes][kStatVals];
     const int v = threadIdx.x % kStatVals, j = threadIdx.x / kStatVals;
     const int c = blockIdx.x * kStatVals + v; // value: sums, then sums of squares
     double t = 0;
     if (c < 2 * step)
-        for (int sgi = j; sgi < numSegs; sgi += kStatLanes) t += partial[(size_t)sgi * 2 * step + c];
+        for (int sgi = j; sgi < numSegs; sgi += kShardLanes) t += partial[(size_t)sgi * 2 * step + c];
     red[j][v] = t;
     __syncthreads();
     if (j == 0 && c < 2 * step) {
         t = 0;
-        for (int q = 0; q < kStatLanes; ++q) t += red[q][v];
+        for (int q = 0; q < kShardLanes; ++q) t += red[q][v];
         sums[c] = t;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * step] = (double)utts[0].ownCount;
@@ -352,50 +497,67 @@ __global__ void k_totals_to_stats(const double *totals, double *stats, int step)
     stats[step + c] = 1.0 / sqrt(var);
 }
 
-template <typename T, int ORD, int DW>
-int launch_one(const StreamArgs<T> &a, size_t lds, hipStream_t st)
+// writeAllBlocks: the write kernel's workgroups take every column block of their segment themselves
+template <typename T, typename KS, typename KW>
+int launch_phases(const StreamArgs<T> &a, KS sums, KW write, std::atomic<bool> (&attrSet)[2][kAttrDevices], size_t lds, hipStream_t st,
+                  bool writeAllBlocks = false)
 {
-    static std::atomic<bool> attrSet[3][kAttrDevices];
-    hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_seg_pass<T, ORD, DW, 0>), attrSet[0]);
-    if (e == hipSuccess) e = lds_limit_once(reinterpret_cast<const void *>(&k_seg_pass<T, ORD, DW, 1>), attrSet[1]);
-    if (e == hipSuccess) e = lds_limit_once(reinterpret_cast<const void *>(&k_seg_pass<T, ORD, DW, 2>), attrSet[2]);
+    hipError_t e = lds_limit_once(reinterpret_cast<const void *>(sums), attrSet[0]);
+    if (e == hipSuccess) e = lds_limit_once(reinterpret_cast<const void *>(write), attrSet[1]);
     if (e != hipSuccess) return (int)e;
-    const dim3 grid(a.numSegs, a.numColBlocks);
+    const dim3 grid(a.numSegs, a.numColBlocks), gridW(a.numSegs, writeAllBlocks ? 1 : a.numColBlocks), block(kSegWaves * 64);
     switch (a.phase) {
     case 0: // batch plan: sums, statistics, finished rows
         if (a.znorm) {
-            hipLaunchKernelGGL((k_seg_pass<T, ORD, DW, 0>), grid, dim3(kSegWaves * 64), lds, st, a);
+            hipLaunchKernelGGL(sums, grid, block, lds, st, a);
             hipLaunchKernelGGL(k_seg_stats, dim3(a.numUtts, (a.step + kStatVals - 1) / kStatVals), dim3(kStatVals * kStatLanes), 0, st,
                                a.partial, a.utts, a.segBegin, a.stats, a.step);
         }
-        hipLaunchKernelGGL((k_seg_pass<T, ORD, DW, 1>), grid, dim3(kSegWaves * 64), lds, st, a);
+        hipLaunchKernelGGL(write, gridW, block, lds, st, a);
         break;
-    case 1: // shard plan, extraction: rows as they are, with the segments' sums when a z-norm follows
-        if (a.znorm) hipLaunchKernelGGL((k_seg_pass<T, ORD, DW, 2>), grid, dim3(kSegWaves * 64), lds, st, a);
-        else hipLaunchKernelGGL((k_seg_pass<T, ORD, DW, 1>), grid, dim3(kSegWaves * 64), lds, st, a);
+    case 1: // shard plan, extraction: with a z-norm to follow only the segments' sums (the rows are
+            // formed by the normalisation call, once the totals of every shard are known); else the rows
+        if (a.znorm) hipLaunchKernelGGL(sums, grid, block, lds, st, a);
+        else hipLaunchKernelGGL(write, gridW, block, lds, st, a);
         break;
-    default: // shard plan, normalisation with the recording's statistics (a.stats)
-        hipLaunchKernelGGL((k_seg_pass<T, ORD, DW, 1>), grid, dim3(kSegWaves * 64), lds, st, a);
+    default: // shard plan, normalisation with the recording's statistics (a.stats): the rows
+        hipLaunchKernelGGL(write, gridW, block, lds, st, a);
         break;
     }
     return (int)hipGetLastError();
 }
 
+template <typename T, int ORD>
+int launch_generic(const StreamArgs<T> &a, size_t lds, hipStream_t st)
+{
+    static std::atomic<bool> attrSet[2][kAttrDevices];
+    return launch_phases<T>(a, &k_seg_pass<T, ORD, 0>, &k_seg_pass<T, ORD, 1>, attrSet, lds, st);
+}
+template <typename T, int ORD, int DW>
+int launch_reg(const StreamArgs<T> &a, size_t lds, hipStream_t st)
+{
+    static std::atomic<bool> attrSet[2][2][kAttrDevices];
+    if (a.colBlock > 32) // one row lane: rows straight from memory
+        return launch_phases<T>(a, &k_seg_reg<T, ORD, DW, 0, true>, &k_seg_reg<T, ORD, DW, 1, true>, attrSet[1], lds, st, true);
+    return launch_phases<T>(a, &k_seg_reg<T, ORD, DW, 0, false>, &k_seg_reg<T, ORD, DW, 1, false>, attrSet[0], lds, st);
+}
+
 template <typename T>
 int launch_t(const StreamArgs<T> &a, int orders, size_t lds, hipStream_t st)
 {
-    // register path: delwin 1 .. 3 with the chunk geometry it needs (stream_finish_geometry)
-    const int fast = (orders >= 2 && a.fastPath) ? a.delwin : 0;
-    switch (orders * 4 + fast) {
-    case 4: return launch_one<T, 1, 0>(a, lds, st);
-    case 8: return launch_one<T, 2, 0>(a, lds, st);
-    case 9: return launch_one<T, 2, 1>(a, lds, st);
-    case 10: return launch_one<T, 2, 2>(a, lds, st);
-    case 11: return launch_one<T, 2, 3>(a, lds, st);
-    case 12: return launch_one<T, 3, 0>(a, lds, st);
-    case 13: return launch_one<T, 3, 1>(a, lds, st);
-    case 14: return launch_one<T, 3, 2>(a, lds, st);
-    case 15: return launch_one<T, 3, 3>(a, lds, st);
+    const int reg = a.fastPath ? a.delwin : 0; // register path: the window lengths stream_finish_geometry names
+    switch (orders * 16 + reg) {
+    case 16: return launch_generic<T, 1>(a, lds, st);
+    case 32: return launch_generic<T, 2>(a, lds, st);
+    case 33: return launch_reg<T, 2, 1>(a, lds, st);
+    case 34: return launch_reg<T, 2, 2>(a, lds, st);
+    case 35: return launch_reg<T, 2, 3>(a, lds, st);
+    case 41: return launch_reg<T, 2, 9>(a, lds, st);
+    case 48: return launch_generic<T, 3>(a, lds, st);
+    case 49: return launch_reg<T, 3, 1>(a, lds, st);
+    case 50: return launch_reg<T, 3, 2>(a, lds, st);
+    case 51: return launch_reg<T, 3, 3>(a, lds, st);
+    case 57: return launch_reg<T, 3, 9>(a, lds, st);
     default: return -2;
     }
 }
@@ -406,32 +568,48 @@ int stream_finish_seg_chunks() { return kSegChunks; }
 
 // Geometry, from the option set alone: column blocks of at most 64 columns (narrower when the halo
 // rows of a long regression window would not fit), rows per chunk, per-wave LDS elements, total
-// bytes.  *fastPath: delwin is 1 .. 3 and a chunk is kFastRows rows per lane (the register path's
-// form); *stageOut: one column block, finished rows leave through LDS as contiguous pieces.
+// bytes.  *fastPath: delwin is one of the register path's (1, 2, 3, 9) and a chunk is reg_rows(delwin)
+// rows per lane; *stageOut: one column block, finished rows leave through LDS as contiguous pieces.
 // false: nothing fits (the caller takes the row-block kernels).
 bool stream_finish_geometry(int vSize, int orders, int delwin, int elemBytes, int wantRows, int *colBlock, int *numColBlocks,
                             int *chunkRows, int *waveElems, int *redOffset, size_t *ldsBytes, int *fastPath, int *stageOut)
 {
     const int h = (orders - 1) * delwin, h1 = orders == 3 ? delwin : 0;
     const size_t budget = 48 * 1024;
-    const bool fast = orders >= 2 && delwin >= 1 && delwin <= 3 && wantRows <= 0;
+    const bool fast = orders >= 2 && (delwin == 1 || delwin == 2 || delwin == 3 || delwin == 9) && wantRows <= 0;
+    if (fast) {
+        // the fewest column blocks whose staging fits; finished rows staged too where that fits
+        for (int nb = (vSize + 63) / 64; nb <= vSize; ++nb) {
+            const int cb = (vSize + nb - 1) / nb, rowLanes = 64 / cb, nblocks = (vSize + cb - 1) / cb;
+            const int rw = reg_rows(delwin) * rowLanes;
+            for (int stage = nblocks == 1 ? 1 : 0; stage >= 0; --stage) {
+                size_t elems = (rowLanes == 1 ? 0 : (((size_t)(rw + 2 * h + 1) * cb + 3) & ~(size_t)3)) + (stage ? (size_t)rw * vSize * orders + 4 : 0);
+                elems = (elems + 3) & ~(size_t)3;
+                const size_t red = (kSegWaves * elems * elemBytes + 15) & ~(size_t)15;
+                const size_t total = red + 2 * kSegWaves * 64 * sizeof(double);
+                if (total <= budget) {
+                    *colBlock = cb, *numColBlocks = nblocks, *chunkRows = rw, *waveElems = (int)elems, *redOffset = (int)red;
+                    *ldsBytes = total, *fastPath = 1, *stageOut = stage;
+                    return true;
+                }
+            }
+            if (cb <= 8) break;
+        }
+    }
     for (int nb = (vSize + 63) / 64; nb <= vSize; nb *= 2) {
-        const int cb = (vSize + nb - 1) / nb, rowLanes = 64 / cb;
+        const int cb = (vSize + nb - 1) / nb;
         const int nblocks = (vSize + cb - 1) / cb;
-        for (int rw = fast ? kFastRows * rowLanes : (wantRows > 0 ? wantRows : 32); rw >= 16 || fast; rw /= 2) {
-            if (!fast && rw < 2 * h && rw < 32 && cb > 8) continue; // (more halo than rows: rather narrower column blocks)
-            const bool stage = fast && nblocks == 1;
-            const size_t statics = ((size_t)(rw + 2 * h) * cb + cb + 3) & ~(size_t)3; // row-major, or column-major with a pitch of rw + 2 h + 1
-            const size_t second = std::max<size_t>(orders >= 2 ? (size_t)(rw + 2 * h1) * cb : 0, stage ? (size_t)rw * vSize * orders + 4 : 0);
-            const size_t elems = (statics + second + 3) & ~(size_t)3;
+        for (int rw = wantRows > 0 ? wantRows : 32; rw >= 16; rw /= 2) {
+            if (rw < 2 * h && rw < 32 && cb > 8) continue; // (more halo than rows: rather narrower column blocks)
+            const size_t elems = ((size_t)(rw + 2 * h) * cb + (orders >= 2 ? (size_t)(rw + 2 * h1) * cb : 0) + 3) & ~(size_t)3;
             const size_t red = (kSegWaves * elems * elemBytes + 15) & ~(size_t)15;
             const size_t total = red + 2 * kSegWaves * 64 * sizeof(double);
             if (total <= budget) {
                 *colBlock = cb, *numColBlocks = nblocks, *chunkRows = rw, *waveElems = (int)elems, *redOffset = (int)red;
-                *ldsBytes = total, *fastPath = fast ? 1 : 0, *stageOut = stage ? 1 : 0;
+                *ldsBytes = total, *fastPath = 0, *stageOut = 0;
                 return true;
             }
-            if (wantRows > 0 || fast) break;
+            if (wantRows > 0) break;
         }
         if (cb <= 4) break;
     }
@@ -440,7 +618,7 @@ bool stream_finish_geometry(int vSize, int orders, int delwin, int elemBytes, in
 
 int launch_seg_shard_sums(const double *partial, const UttDesc *utts, int numSegs, double *sums, int step, void *stream)
 {
-    hipLaunchKernelGGL(k_seg_shard_sums, dim3((2 * step + kStatVals - 1) / kStatVals), dim3(kStatVals * kStatLanes), 0,
+    hipLaunchKernelGGL(k_seg_shard_sums, dim3((2 * step + kStatVals - 1) / kStatVals), dim3(kStatVals * kShardLanes), 0,
                        static_cast<hipStream_t>(stream), partial, utts, numSegs, sums, step);
     return (int)hipGetLastError();
 }

@@ -15,12 +15,16 @@ from mfcc_amd.presets import CONFIGS
 pytestmark = pytest.mark.gpu
 
 
-def _sums_with_plan(ctx, ch, bps, dev_pcm, n):
-    """The existing entry point: a shard plan that owns every frame of the recording."""
-    plan = ma.Plan(ctx, ch, bps, shard=(n, 0, ma.num_frames(n, ctx.cfg.wlen, ctx.cfg.inc), None))
+def _sums_with_plan(ctx, ctx_plain, ch, bps, dev_pcm, n):
+    """The existing entry point: a shard plan that owns every frame of the recording.  Returns the
+    un-normalised matrix (from the same plan without z-norm: a shard plan with z-norm leaves the
+    matrix to its normalisation call) and the plan's sums."""
+    frames = ma.num_frames(n, ctx.cfg.wlen, ctx.cfg.inc)
+    plan = ma.Plan(ctx, ch, bps, shard=(n, 0, frames, None))
     out = plan.extract(dev_pcm)
     sums = plan.shard_column_sums(out)
-    return out, sums
+    plain = ma.Plan(ctx_plain, ch, bps, shard=(n, 0, frames, None))
+    return plain.extract(dev_pcm), sums
 
 
 def _sums_no_alloc(out, step, prec):
@@ -39,12 +43,13 @@ def test_no_alloc_column_sums_match_the_plan_entry_point(precision):
     prec = ma.PREC_F64 if precision == "f64" else ma.PREC_F32
     cfg = ma.make_config(precision=prec, **kw)
     ctx = ma.Context(cfg, 0)
+    ctx_plain = ma.Context(ma.make_config(precision=prec, **dict(kw, znormFlag=0)), 0)
     ch, bps = 2, 3
     # two calls in a row, the second with a smaller input (fewer rows, fewer chunks)
     for n in (44100 * 7 + 311, 44100 * 2 + 17):
         pcm = ma.synth_pcm(n, ch, bps, seed=0x5EED0000 + n, sample_rate=44100, tone_hz=440)
         dev = torch.from_numpy(pcm).cuda()
-        out, want = _sums_with_plan(ctx, ch, bps, dev, n)
+        out, want = _sums_with_plan(ctx, ctx_plain, ch, bps, dev, n)
         got = _sums_no_alloc(out, ctx.step, prec)
         torch.cuda.synchronize()
         w, g = want.cpu().numpy(), got.cpu().numpy()
