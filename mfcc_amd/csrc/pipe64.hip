@@ -113,11 +113,84 @@ __device__ __forceinline__ double frame_sum(double v)
 template <int G>
 __device__ __forceinline__ int frame_sum(int v) { return group_sum<int, G>(v, nullptr, 0); }
 
+// lane i takes x of lane i + 1; lane 63 takes `last`
+__device__ __forceinline__ double wave_shl1d(double x, double last)
+{
+    const long long xb = __double_as_longlong(x), lb = __double_as_longlong(last);
+    const int lo = __builtin_amdgcn_update_dpp((int)lb, (int)xb, 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(lb >> 32), (int)(xb >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// 1024-point class: the lane's sample pairs (2n, 2n+1), n = l + 64 r, of derived row ROW (0 L, 1 R,
+// 2 mid = 0.5 (L+R), 3 side = L - R; main.c:198-207) from the frame's raw 24-bit stereo bytes:
+// instants 2n-1 (the predecessor), 2n, 2n+1 of both channels are 18 bytes from byte 12 n on.
+// Pre-emphasis over the whole signal in double with separately rounded product and difference
+// (PreEmphasise main.c:208; first-sample rule for the signal's first sample), Hamming window
+// (main.c:229); with ZC the zero crossings of the un-windowed samples (main.c:227), counted over the
+// wave with mask popcounts (sample 2n+2 is the next lane's first sample).  Every read is issued
+// before the arithmetic; no branch inside.
+template <int NZ, bool ZC, int ROW>
+__device__ __forceinline__ void pipe_expand_wide(cpx<double> (&v)[16], int &zc, const unsigned *rawLane, int l, const cpx<double> *winLane,
+                                                 double preK, bool firstTile, int wlen)
+{
+    constexpr int G = 64;
+    unsigned own[NZ][5];
+    cpx<double> w[NZ];
+#pragma unroll
+    for (int r = 0; r < NZ; ++r) {
+        const unsigned *src = rawLane + 3 * G * r;
+        const u4u q = *reinterpret_cast<const u4u *>(src);
+        own[r][0] = q.x, own[r][1] = q.y, own[r][2] = q.z, own[r][3] = q.w;
+        own[r][4] = src[4];
+    }
+#pragma unroll
+    for (int r = 0; r < NZ; ++r) w[r] = winLane[G * r];
+    double nextFirst0 = 0; // sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r)
+#pragma unroll
+    for (int r = NZ - 1; r >= 0; --r) {
+        const unsigned(&d)[5] = own[r];
+        int c[3];
+        if constexpr (ROW == 0) {
+            c[0] = window_sample<3, 0, 5>(d), c[1] = window_sample<3, 6, 5>(d), c[2] = window_sample<3, 12, 5>(d);
+        } else if constexpr (ROW == 1) {
+            c[0] = window_sample<3, 3, 5>(d), c[1] = window_sample<3, 9, 5>(d), c[2] = window_sample<3, 15, 5>(d);
+        } else if constexpr (ROW == 2) { // L + R, halved below (the integer sum is exact)
+            c[0] = window_sample<3, 0, 5>(d) + window_sample<3, 3, 5>(d), c[1] = window_sample<3, 6, 5>(d) + window_sample<3, 9, 5>(d);
+            c[2] = window_sample<3, 12, 5>(d) + window_sample<3, 15, 5>(d);
+        } else {
+            c[0] = window_sample<3, 0, 5>(d) - window_sample<3, 3, 5>(d), c[1] = window_sample<3, 6, 5>(d) - window_sample<3, 9, 5>(d);
+            c[2] = window_sample<3, 12, 5>(d) - window_sample<3, 15, 5>(d);
+        }
+        double x[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) x[i] = ROW == 2 ? 0.5 * (double)c[i] : (double)c[i];
+        double y1 = sub_mul_exact(x[1], x[0], preK);
+        const double y2 = sub_mul_exact(x[2], x[1], preK);
+        if (firstTile && l == 0 && r == 0) y1 = x[1] * (1.0 - preK); // s[1] *= 1 - k
+        if constexpr (ZC) {
+            const double x2 = wave_shl1d(y1, nextFirst0);
+            // (opposite signs = negative product; the samples are far from the underflow range)
+            bool c01 = y1 * y2 < 0.0, c12 = y2 * x2 < 0.0;
+            // pairs inside the frame only (an instance serves every window length up to 128 NZ)
+            const int s0 = 2 * (l + G * r);
+            c01 = c01 && s0 + 1 < wlen;
+            c12 = c12 && s0 + 2 < wlen;
+            zc += __builtin_popcountll(__builtin_amdgcn_ballot_w64(c01)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c12));
+            const long long yb = __double_as_longlong(y1);
+            nextFirst0 = __longlong_as_double(((long long)sgpr((int)(yb >> 32)) << 32) | (unsigned)sgpr((int)yb));
+        }
+        v[r] = cpx<double>{y1 * w[r].x, y2 * w[r].y};
+    }
+#pragma unroll
+    for (int r = NZ; r < 16; ++r) v[r] = cpx<double>{0.0, 0.0};
+}
+
 } // namespace
 
 // LOG2NC: 8 (CH 1, BPS 2) or 10 (CH 2, BPS 3).  NZ: first-stage inputs of a lane that can be
-// non-zero, ceil(wlen / (2 G)).
-template <int LOG2NC, int CH, int BPS, int NZ>
+// non-zero, ceil(wlen / (2 G)).  ZCT (1024-point class): zero-crossing rate on.
+template <int LOG2NC, int CH, int BPS, int NZ, bool ZCT>
 __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<double> a)
 {
     constexpr int NC = 1 << LOG2NC, G = NC / 16, GT = 64 / G, PPL = 16, NPAIR = 8, WAVES = kPipeWaves;
@@ -344,6 +417,16 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         //      samples (main.c:227), Hamming window (main.c:229), frame energy (mfcc.c:138-142)
         cpx<T> v[PPL];
         int zcn = 0;
+        if constexpr (G == 64) {
+            const unsigned *rawLane = raw + 3 * l;
+            const cpx<T> *winLane = winT + lq;
+            switch (vv) { // (the same for every lane)
+            case 0: pipe_expand_wide<NZ, ZCT, 0>(v, zcn, rawLane, l, winLane, preK, firstTile, a.wlen); break;
+            case 1: pipe_expand_wide<NZ, ZCT, 1>(v, zcn, rawLane, l, winLane, preK, firstTile, a.wlen); break;
+            case 2: pipe_expand_wide<NZ, ZCT, 2>(v, zcn, rawLane, l, winLane, preK, firstTile, a.wlen); break;
+            default: pipe_expand_wide<NZ, ZCT, 3>(v, zcn, rawLane, l, winLane, preK, firstTile, a.wlen); break;
+            }
+        } else
         {
             // instants 2n-1 (predecessor), 2n, 2n+1, 2n+2 start at byte (frame start + 2n) BPI
             const unsigned *src = raw + (CH == 1 ? ((fr * a.inc) >> 1) + l : 3 * l);
@@ -401,7 +484,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
             for (int r = 0; r < NZ; ++r) e2 += v[r] * v[r];
             te = frame_sum<G>((T)4 * (e2.x + e2.y)); // (the window table holds half the Hamming values)
         }
-        if (a.zcFlag) zcn = frame_sum<G>(zcn);
+        if (G == 16 && a.zcFlag) zcn = frame_sum<G>(zcn); // (1024-point class: counted over the wave already)
         STAMP(1);
 
         // ---- NC-point complex FFT of z[n] = x[2n] + i x[2n+1] (Realft mfcc.c:262-270): Stockham
@@ -761,13 +844,13 @@ int pipe64_tab_elems(int cls, int wlen, int dctElems, int melSteps)
     return (n + 1) & ~1;
 }
 
-template <int LOG2NC, int CH, int BPS, int NZ>
+template <int LOG2NC, int CH, int BPS, int NZ, bool ZCT>
 static int launch_pipe_t(const FrontArgs<double> &a, int numBlocks, size_t lds, hipStream_t st)
 {
     static std::atomic<bool> attrSet[kAttrDevices];
-    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_pipe64<LOG2NC, CH, BPS, NZ>), attrSet);
+    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_pipe64<LOG2NC, CH, BPS, NZ, ZCT>), attrSet);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_pipe64<LOG2NC, CH, BPS, NZ>), dim3(numBlocks), dim3(kPipeWaves * 64), lds, st, a);
+    hipLaunchKernelGGL((k_pipe64<LOG2NC, CH, BPS, NZ, ZCT>), dim3(numBlocks), dim3(kPipeWaves * 64), lds, st, a);
     return (int)hipGetLastError();
 }
 
@@ -775,8 +858,9 @@ int launch_pipe64(const FrontArgs<double> &a, int cls, int numBlocks, size_t lds
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nz = pipe64_nz(cls, a.wlen);
-    if (cls == 8) return nz == 13 ? launch_pipe_t<8, 1, 2, 13>(a, numBlocks, lds, st) : launch_pipe_t<8, 1, 2, 16>(a, numBlocks, lds, st);
-    return nz == 14 ? launch_pipe_t<10, 2, 3, 14>(a, numBlocks, lds, st) : launch_pipe_t<10, 2, 3, 16>(a, numBlocks, lds, st);
+    if (cls == 8) return nz == 13 ? launch_pipe_t<8, 1, 2, 13, false>(a, numBlocks, lds, st) : launch_pipe_t<8, 1, 2, 16, false>(a, numBlocks, lds, st);
+    if (a.zcFlag) return nz == 14 ? launch_pipe_t<10, 2, 3, 14, true>(a, numBlocks, lds, st) : launch_pipe_t<10, 2, 3, 16, true>(a, numBlocks, lds, st);
+    return nz == 14 ? launch_pipe_t<10, 2, 3, 14, false>(a, numBlocks, lds, st) : launch_pipe_t<10, 2, 3, 16, false>(a, numBlocks, lds, st);
 }
 
 } // namespace mfcc
