@@ -87,6 +87,20 @@ typedef struct MFCCConfig {
 /* Thread-local message of the last failed call ("" if none). */
 const char *MFCCLastError(void);
 
+/* Work counters of the process (the reference only prints progress lines, main.c:180-187,212,252,274):
+ * what the extraction entry points have done since the process started or the last reset.
+ * frames / pcmBytes / featureBytes: rows produced, PCM bytes consumed and feature bytes produced by
+ * MFCCExtractDevice (every entry point extracts through it; a shard plan counts the rows it owns);
+ * filesOk / filesFailed: files through MFCCWapper, MFCCWapperMem and MFCCWapperList;
+ * listSeconds / recordingSeconds: wall time spent inside MFCCWapperList / MFCCExtractRecording, so
+ * that frames / listSeconds is the end-to-end rate of a list run.  Thread-safe. */
+typedef struct MFCCCounters {
+    uint64_t extractCalls, frames, pcmBytes, featureBytes, filesOk, filesFailed;
+    double listSeconds, recordingSeconds;
+} MFCCCounters;
+void MFCCCountersGet(MFCCCounters *out);
+void MFCCCountersReset(void);
+
 /* Releases any buffer this library handed out (feature matrices). */
 void MFCCFree(void *p);
 

@@ -60,6 +60,21 @@ class MFCCConfig(C.Structure):
     ]
 
 
+class MFCCCounters(C.Structure):
+    """include/mfcc_amd.h: MFCCCounters."""
+    _fields_ = [("extractCalls", C.c_uint64), ("frames", C.c_uint64), ("pcmBytes", C.c_uint64), ("featureBytes", C.c_uint64),
+                ("filesOk", C.c_uint64), ("filesFailed", C.c_uint64), ("listSeconds", C.c_double), ("recordingSeconds", C.c_double)]
+
+
+def counters(reset=False):
+    """The library's work counters as a dict (MFCCCountersGet); reset=True zeroes them afterwards."""
+    c = MFCCCounters()
+    lib().MFCCCountersGet(C.byref(c))
+    if reset:
+        lib().MFCCCountersReset()
+    return {name: getattr(c, name) for name, _ in MFCCCounters._fields_}
+
+
 class MFCCError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("mfcc_amd error %d: %s" % (code, message))
@@ -76,7 +91,7 @@ EXPORTS = [
     "MFCCContextPassbandText", "MFCCContextTables", "MFCCPlanCreate", "MFCCPlanCreateShard",
     "MFCCPlanDestroy", "MFCCShardGeometry", "MFCCPlanTotalRows", "MFCCPlanRowOffset", "MFCCPlanNumFrames",
     "MFCCPlanSampleBegin", "MFCCPlanSampleCount", "MFCCPlanOwnedRowBegin", "MFCCPlanOwnedRows",
-    "MFCCExtractDevice", "MFCCExtractRecording", "MFCCColumnSumsNoAlloc", "MFCCColumnSumsNoAllocWarmup", "MFCCShardExchange", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
+    "MFCCExtractDevice", "MFCCExtractRecording", "MFCCColumnSumsNoAlloc", "MFCCColumnSumsNoAllocWarmup", "MFCCShardExchange", "MFCCCountersGet", "MFCCCountersReset", "MFCCShardColumnSums", "MFCCShardNormalize", "MFCCChannelSums",
     "MFCCPlanEnableTiming", "MFCCPlanLastKernelMs", "MFCCDebugTuning", "MFCCSynthPcm", "MFCCSynthPcmAt", "MFCCFormatValue",
     "MFCCFFTDevice", "MFCCRealftDevice", "MFCCWave2FBankDevice", "MFCCFBank2MFCCDevice", "MFCCMel",
     "MFCCFBankTables", "MFCCWave2FBankTablesDevice", "MFCCFBank2MFCCDirectDevice",
@@ -142,6 +157,10 @@ def lib():
     L.MFCCColumnSumsNoAlloc.argtypes = [C.c_int, vp, C.c_int64, C.c_int, vp, vp]
     L.MFCCColumnSumsNoAllocWarmup.argtypes = []
     L.MFCCShardExchange.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+    L.MFCCCountersGet.argtypes = [vp]
+    L.MFCCCountersGet.restype = None
+    L.MFCCCountersReset.argtypes = []
+    L.MFCCCountersReset.restype = None
     L.MFCCShardNormalize.argtypes = [vp, vp, vp, vp, vp]
     L.MFCCChannelSums.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp]
     L.MFCCPlanEnableTiming.argtypes = [vp, C.c_int]

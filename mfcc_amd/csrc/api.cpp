@@ -297,6 +297,39 @@ extern "C" int MFCCDebugTuning(const char *key, int value)
 }
 
 // ------------------------------------------------------------------------------------------
+// Process-wide work counters (the reference only prints progress, main.c:180-187,212,252,274):
+// what the extraction entry points have been asked to do since the process started or since the
+// last MFCCCountersReset.
+// ------------------------------------------------------------------------------------------
+
+namespace {
+struct Counters {
+    std::atomic<uint64_t> extractCalls{0}, frames{0}, pcmBytes{0}, featureBytes{0}, filesOk{0}, filesFailed{0};
+    std::atomic<uint64_t> listNanos{0}, recordingNanos{0};
+};
+Counters g_count;
+} // namespace
+
+extern "C" void MFCCCountersGet(MFCCCounters *out)
+{
+    if (!out) return;
+    out->extractCalls = g_count.extractCalls.load();
+    out->frames = g_count.frames.load();
+    out->pcmBytes = g_count.pcmBytes.load();
+    out->featureBytes = g_count.featureBytes.load();
+    out->filesOk = g_count.filesOk.load();
+    out->filesFailed = g_count.filesFailed.load();
+    out->listSeconds = (double)g_count.listNanos.load() * 1e-9;
+    out->recordingSeconds = (double)g_count.recordingNanos.load() * 1e-9;
+}
+
+extern "C" void MFCCCountersReset(void)
+{
+    g_count.extractCalls = 0, g_count.frames = 0, g_count.pcmBytes = 0, g_count.featureBytes = 0;
+    g_count.filesOk = 0, g_count.filesFailed = 0, g_count.listNanos = 0, g_count.recordingNanos = 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // plans
 // ------------------------------------------------------------------------------------------
 
@@ -1668,6 +1701,14 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
     DEVICE_SCOPE(c->device);
     TraceRange range("MFCCExtractDevice");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        uint64_t pcm = 0;
+        for (const UttDesc &d : p->utts) pcm += (uint64_t)d.numInstants * (uint64_t)bpi;
+        g_count.extractCalls += 1;
+        g_count.frames += (uint64_t)p->ownedRows;
+        g_count.pcmBytes += pcm;
+        g_count.featureBytes += (uint64_t)p->ownedRows * (uint64_t)c->step * (c->cfg.precision == MFCC_PREC_F64 ? 8u : 4u);
+    }
     int rc;
     if (c->cfg.zeroMeanSigFlag && !p->shard) {
         HIP_TRY(hipMemsetAsync(p->dSums2, 0, (size_t)p->numUtts * 4 * sizeof(unsigned long long), st));
@@ -1683,6 +1724,8 @@ extern "C" int MFCCExtractDevice(MFCCContext *c, MFCCPlan *p, const void *pcmDev
     if (p->timing) HIP_TRY(hipEventRecord(p->evStart, st));
     void *frontOut = p->uttFinish ? p->dStatics : outDev;
     const int frontStep = p->uttFinish ? c->vSize : c->step;
+    if (p->uttFinish && tuning().debug == 2) // diagnostic: static features no kernel writes show as NaN
+        HIP_TRY(hipMemsetAsync(p->dStatics, 0xFF, (size_t)p->totalRows * c->vSize * (f64 ? 8 : 4), st));
     rc = f64 ? run_front<double>(c, p, pcmDev, frontOut, frontStep, stream)
              : run_front<float>(c, p, pcmDev, frontOut, frontStep, stream);
     if (rc) return rc;
@@ -1991,8 +2034,19 @@ int extract_packed(MFCCContext *c, const unsigned char *packed, size_t packedByt
 
 } // namespace
 
+static int wapper_mem(const MFCCConfig *cfg, const void *wavFile, size_t wavLen, const char *outPath, double **features,
+                      long *numFrames, int *step);
+
 extern "C" int MFCCWapperMem(const MFCCConfig *cfg, const void *wavFile, size_t wavLen,
                              const char *outPath, double **features, long *numFrames, int *step)
+{
+    const int rc = wapper_mem(cfg, wavFile, wavLen, outPath, features, numFrames, step);
+    (rc == MFCC_OK ? g_count.filesOk : g_count.filesFailed) += 1;
+    return rc;
+}
+
+static int wapper_mem(const MFCCConfig *cfg, const void *wavFile, size_t wavLen, const char *outPath, double **features,
+                      long *numFrames, int *step)
 {
     if (features) *features = nullptr;
     if (numFrames) *numFrames = 0;
@@ -2033,7 +2087,10 @@ extern "C" int MFCCWapper(const MFCCConfig *cfg, const char *wavPath, const char
     if (!cfg || !wavPath) return set_error("NULL argument"), MFCC_E_ARG;
     std::vector<unsigned char> file;
     const int rc = read_file(wavPath, file);
-    if (rc) return rc;
+    if (rc) {
+        g_count.filesFailed += 1;
+        return rc;
+    }
     return MFCCWapperMem(cfg, file.data(), file.size(), outPath, features, numFrames, step);
 }
 
@@ -2194,6 +2251,7 @@ extern "C" int MFCCWapperList(const char *iniPath)
     if (rc) return rc;
     const bool quiet = getenv("MFCC_QUIET") != nullptr;
     const bool timing = getenv("MFCC_LIST_TIMING") != nullptr;
+    const double tList0 = now_s();
     if (!quiet) printf("finish reading the config.ini\n"); /* main.c:140 */
     CtxRef cref; // held until the list is done
     if ((rc = cached_context(cfg, &cref))) return rc;
@@ -2426,6 +2484,9 @@ extern "C" int MFCCWapperList(const char *iniPath)
             ++failed;
             fprintf(stderr, "mfcc: %s: %s (code %d)\n", it.src.c_str(), it.message.c_str(), it.status);
         }
+    g_count.filesFailed += (uint64_t)failed;
+    g_count.filesOk += (uint64_t)(items.size() - (size_t)failed);
+    g_count.listNanos += (uint64_t)((now_s() - tList0) * 1e9);
     if (failed) set_error("%d of %zu files failed", failed, items.size());
     return failed;
 }
@@ -2477,6 +2538,7 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
     if (channels < 1 || channels > 2 || bytesPerSample < 1 || bytesPerSample > 4)
         return set_error("unsupported PCM layout: %d channels x %d bytes", channels, bytesPerSample), MFCC_E_WAV;
     const MFCCConfig cfg = *cfgIn;
+    const double tRec0 = now_s();
     int rc = validate_config(cfg);
     if (rc) return rc;
     int visible = 0, current = 0;
@@ -2643,6 +2705,7 @@ extern "C" int MFCCExtractRecording(const MFCCConfig *cfgIn, const void *pcm, in
     for (int g = 1; g < S; ++g) threads.emplace_back(shard, g);
     shard(0);
     for (auto &th : threads) th.join();
+    g_count.recordingNanos += (uint64_t)((now_s() - tRec0) * 1e9);
     for (void *cm : comms) rccl_comm_destroy(cm);
     if (pinnedPcm) (void)hipHostUnregister(const_cast<void *>(pcm));
     if (pinnedOut) (void)hipHostUnregister(features);

@@ -217,17 +217,12 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_reg(const StreamArgs<T> 
     const int2 sg = reinterpret_cast<const int2 *>(a.segs)[blockIdx.x];
     const UttDesc ud = a.utts[sg.x];
     const int n = ud.numFrames;
-    // The straight-from-memory form writes every column block of its rows itself, one after the
-    // other (the pieces of an output row then reach the cache together and leave it as whole lines);
-    // otherwise a workgroup has one column block (blockIdx.y).
-    constexpr bool ALLBLOCKS = DIRECT && WRITE;
-    const int cbBegin = ALLBLOCKS ? 0 : (int)blockIdx.y, cbEnd = ALLBLOCKS ? a.numColBlocks : (int)blockIdx.y + 1;
-    int c0 = cbBegin * a.colBlock;
-    int CB = min(a.colBlock, W - c0);
+    const int c0 = blockIdx.y * a.colBlock;
+    const int CB = min(a.colBlock, W - c0);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int rowLanes = 64 / a.colBlock;
     const int col = lane % a.colBlock, rl = lane / a.colBlock;
-    bool live = rl < rowLanes && col < CB;
+    const bool live = rl < rowLanes && col < CB;
     constexpr bool direct = DIRECT; // (one row lane: rowLanes == 1)
 
     // LDS (staged form): per wave [statics colBlock x (RW + 2 HH + 1) | RW finished rows], then the
@@ -238,7 +233,7 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_reg(const StreamArgs<T> 
     const int pitch = RW + 2 * HH + 1; // (odd pitches spread the columns over the banks)
 
     const T *src = a.statics + ud.outRow * W + c0;
-    T *dst = a.out + ud.outRow * step + c0; // (of the current column block)
+    T *dst = a.out + ud.outRow * step + c0;
     const SegCommon<T> cm = {a.sigmaT2, 1.0 / a.sigmaT2};
     const int segEnd = min(n, sg.y + kSegChunks * RW);
 
@@ -263,9 +258,7 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_reg(const StreamArgs<T> 
 
     // rows are addressed from the segment's first halo row (a uniform base and a 32-bit offset per lane)
     const int segRow0 = sg.y - HH;
-    const T *segBase = src + (long long)segRow0 * W; // (of the current column block)
-    const T *segBase0 = segBase - c0;
-    T *dst0 = dst - c0;
+    const T *segBase = src + (long long)segRow0 * W;
     // staged form: the rows of a chunk on their way from memory (row rl + i rowLanes of it in pf[i])
     constexpr int NPF = PREFETCH ? NS : 1;
     T pf[NPF];
@@ -295,17 +288,6 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_reg(const StreamArgs<T> 
     T *stageP = stage + mis;
 
     for (int s = sg.y + wave * RW; s < segEnd; s += kSegWaves * RW) {
-      for (int cbk = cbBegin; cbk < cbEnd; ++cbk) {
-        if constexpr (ALLBLOCKS) {
-            if (a.numColBlocks > 1) {
-                c0 = cbk * a.colBlock;
-                CB = min(a.colBlock, W - c0);
-                live = col < CB;
-                segBase = segBase0 + c0;
-                dst = dst0 + c0;
-                load_stats();
-            }
-        }
         const int rows = min(RW, n - s);
         const int r0 = s + rl * K; // the lane's first row
         T sv[NS];                  // statics of rows r0 - HH .. r0 + K + HH - 1, each at its clamped row
@@ -354,15 +336,22 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_reg(const StreamArgs<T> 
                 }
                 if constexpr (ORD >= 3) {
                     if (s - HH < 0 || s + RW + HH > n) { // (wave-uniform) the chunk touches an end of the utterance
-                        const int m0 = HH1 - r0, m1 = n - 1 - r0 + HH1; // where rows 0 and n - 1 sit in dv
-                        T dLo = dv[0], dHi = dv[ND - 1];
+                        // first deltas of the utterance's first and last row, from memory (clamped rows;
+                        // addressed from the utterance's first row: row 0 can lie far before the segment)
+                        T sumLo = 0, sumHi = 0;
+#pragma unroll
+                        for (int tau = 1; tau <= DW; ++tau) {
+                            const T a0 = src[(long long)min(tau, n - 1) * W + col], b0 = src[col];
+                            const T a1 = src[(long long)(n - 1) * W + col], b1 = src[(long long)max(n - 1 - tau, 0) * W + col];
+                            sumLo = fma_t((T)tau, a0 - b0, sumLo);
+                            sumHi = fma_t((T)tau, a1 - b1, sumHi);
+                        }
+                        const T dLo = cm.quotient(sumLo), dHi = cm.quotient(sumHi);
 #pragma unroll
                         for (int m = 0; m < ND; ++m) {
-                            dLo = m == m0 ? dv[m] : dLo;
-                            dHi = m == m1 ? dv[m] : dHi;
+                            const int g = r0 - HH1 + m; // the row of dv[m]
+                            dv[m] = g < 0 ? dLo : (g > n - 1 ? dHi : dv[m]);
                         }
-#pragma unroll
-                        for (int m = 0; m < ND; ++m) dv[m] = m < m0 ? dLo : (m > m1 ? dHi : dv[m]);
                     }
                 }
             }
@@ -421,7 +410,6 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_reg(const StreamArgs<T> 
             }
         }
         if (!direct) wave_sync_lds(); // the chunk's rows are consumed before the next chunk overwrites them
-      }
     }
     if constexpr (SUMS)
         seg_reduce<ORD>(s1, s2, red, a.partial + (size_t)blockIdx.x * 2 * step + c0, live, tid, CB, a.colBlock, rowLanes, W, step);
@@ -497,15 +485,13 @@ __global__ void k_totals_to_stats(const double *totals, double *stats, int step)
     stats[step + c] = 1.0 / sqrt(var);
 }
 
-// writeAllBlocks: the write kernel's workgroups take every column block of their segment themselves
 template <typename T, typename KS, typename KW>
-int launch_phases(const StreamArgs<T> &a, KS sums, KW write, std::atomic<bool> (&attrSet)[2][kAttrDevices], size_t lds, hipStream_t st,
-                  bool writeAllBlocks = false)
+int launch_phases(const StreamArgs<T> &a, KS sums, KW write, std::atomic<bool> (&attrSet)[2][kAttrDevices], size_t lds, hipStream_t st)
 {
     hipError_t e = lds_limit_once(reinterpret_cast<const void *>(sums), attrSet[0]);
     if (e == hipSuccess) e = lds_limit_once(reinterpret_cast<const void *>(write), attrSet[1]);
     if (e != hipSuccess) return (int)e;
-    const dim3 grid(a.numSegs, a.numColBlocks), gridW(a.numSegs, writeAllBlocks ? 1 : a.numColBlocks), block(kSegWaves * 64);
+    const dim3 grid(a.numSegs, a.numColBlocks), block(kSegWaves * 64);
     switch (a.phase) {
     case 0: // batch plan: sums, statistics, finished rows
         if (a.znorm) {
@@ -513,15 +499,15 @@ int launch_phases(const StreamArgs<T> &a, KS sums, KW write, std::atomic<bool> (
             hipLaunchKernelGGL(k_seg_stats, dim3(a.numUtts, (a.step + kStatVals - 1) / kStatVals), dim3(kStatVals * kStatLanes), 0, st,
                                a.partial, a.utts, a.segBegin, a.stats, a.step);
         }
-        hipLaunchKernelGGL(write, gridW, block, lds, st, a);
+        hipLaunchKernelGGL(write, grid, block, lds, st, a);
         break;
     case 1: // shard plan, extraction: with a z-norm to follow only the segments' sums (the rows are
             // formed by the normalisation call, once the totals of every shard are known); else the rows
         if (a.znorm) hipLaunchKernelGGL(sums, grid, block, lds, st, a);
-        else hipLaunchKernelGGL(write, gridW, block, lds, st, a);
+        else hipLaunchKernelGGL(write, grid, block, lds, st, a);
         break;
     default: // shard plan, normalisation with the recording's statistics (a.stats): the rows
-        hipLaunchKernelGGL(write, gridW, block, lds, st, a);
+        hipLaunchKernelGGL(write, grid, block, lds, st, a);
         break;
     }
     return (int)hipGetLastError();
@@ -538,7 +524,7 @@ int launch_reg(const StreamArgs<T> &a, size_t lds, hipStream_t st)
 {
     static std::atomic<bool> attrSet[2][2][kAttrDevices];
     if (a.colBlock > 32) // one row lane: rows straight from memory
-        return launch_phases<T>(a, &k_seg_reg<T, ORD, DW, 0, true>, &k_seg_reg<T, ORD, DW, 1, true>, attrSet[1], lds, st, true);
+        return launch_phases<T>(a, &k_seg_reg<T, ORD, DW, 0, true>, &k_seg_reg<T, ORD, DW, 1, true>, attrSet[1], lds, st);
     return launch_phases<T>(a, &k_seg_reg<T, ORD, DW, 0, false>, &k_seg_reg<T, ORD, DW, 1, false>, attrSet[0], lds, st);
 }
 

@@ -1087,6 +1087,40 @@ def test_shard_exchange_entry_point_on_a_one_rank_communicator():
     rccl.ncclCommDestroy(comm)
 
 
+def test_library_counters_follow_the_work(tmp_path):
+    """MFCCCountersGet: frames, PCM bytes and feature bytes of the extractions, files through the
+    per-file and list entry points, wall time of the list run."""
+    kw = CONFIGS["c3"]
+    cfg = ma.make_config(**kw)  # double precision: 8-byte features
+    ma.counters(reset=True)
+    pcm = _pcm(16000 + 40, 1, 2, 77, 16000)
+    wav = ma.wav_bytes(pcm, 1, 2, 16000)
+    feat = ma.wapper_mem(cfg, wav)
+    c = ma.counters()
+    assert c["extractCalls"] == 1 and c["filesOk"] == 1 and c["filesFailed"] == 0
+    assert c["frames"] == feat.shape[0] == ma.num_frames(16040, 400, 160)
+    assert c["pcmBytes"] == 16040 * 2 and c["featureBytes"] == feat.size * 8
+    with pytest.raises(ma.MFCCError):
+        ma.wapper_mem(cfg, wav[:20])
+    assert ma.counters()["filesFailed"] == 1
+    lines = []
+    for i in range(3):
+        (tmp_path / ("a%d.wav" % i)).write_bytes(wav)
+        lines.append("%s\t%s" % (tmp_path / ("a%d.wav" % i), tmp_path / ("a%d.txt" % i)))
+    lines.append("%s\t%s" % (tmp_path / "missing.wav", tmp_path / "m.txt"))
+    (tmp_path / "l.txt").write_text("\n".join(lines) + "\n")
+    ini = tmp_path / "c.ini"
+    ini.write_text("[Frame]\nsampleRate = 16000\nwlen = 400\ninc = 160\nsaveType = b\nfileList = %s\n[MFCC]\nMFCCNum = 12\n" % (tmp_path / "l.txt"))
+    os.environ["MFCC_QUIET"] = "1"
+    try:
+        ma.counters(reset=True)
+        assert ma.wapper_list(str(ini)) == 1
+    finally:
+        del os.environ["MFCC_QUIET"]
+    c = ma.counters()
+    assert c["filesOk"] == 3 and c["filesFailed"] == 1 and c["frames"] == 3 * feat.shape[0] and c["listSeconds"] > 0
+
+
 def test_command_line_program_matches_the_per_file_entry_point(tmp_path):
     """The drop-in program (`mfcc config.ini`, README.md:26) on an example/config.ini-shaped run:
     its files equal MFCCWapper's byte for byte, and its console carries the reference's lines

@@ -53,9 +53,23 @@ for u, (g, r) in enumerate(zip(gots, refs)):
     if r.shape[0] == 0:
         continue
     m = np.where(kinds == "mel")[0]
+    if m.size == 0:
+        continue
     d = np.abs(g[:, m] - r[:, m])
     i, j = np.unravel_index(np.argmax(d), d.shape)
     c = m[j] % len(column_kinds(kw))
     bins = int(np.sum((t["loChan"] == c) | (t["loChan"] == c + 1)))
     print("utt %d: max |d log-mel| %.3g at frame %d column %d (channel %d of vec %d, %d bins): ref %.6f, row max %.3f" % (
         u, d[i, j], i, m[j], c + 1, m[j] // len(column_kinds(kw)), bins, r[i, m[j]], np.max(r[i, m])))
+# where the whole matrix differs most (any column kind, delta blocks included)
+for u, (g, r) in enumerate(zip(gots, refs)):
+    if r.shape[0] == 0:
+        continue
+    fin = np.isfinite(r)
+    d = np.where(fin, np.abs(g - r), 0.0)
+    i, j = np.unravel_index(np.argmax(d), d.shape)
+    vs = len(kinds)
+    rows = np.unique(np.nonzero(d > 1e-3)[0])
+    cols = np.unique(np.nonzero(d > 1e-3)[1])
+    print("utt %d (%d rows): max |d| %.3g at row %d column %d (block %d, column %d of it); rows off by > 1e-3: %s; columns: %s" % (
+        u, r.shape[0], d[i, j], i, j, j // vs, j % vs, rows[:20], cols[:20]))
