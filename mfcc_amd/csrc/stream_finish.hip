@@ -1,17 +1,20 @@
 // Segment-streaming finishing pass of batch plans: regression deltas (Regress, call sites
 // main.c:259-260) and the per-utterance z-norm (README.md:122; commented calls main.c:263-266) for
-// utterances of any length, ragged batches included.  The static-feature kernel writes its rows
-// compactly (numFrames x vSize) into a plan-owned buffer.  Every utterance is cut into segments of
-// 8 chunks of rows, at multiples of the segment length from the utterance's own first row; one
-// workgroup of four waves owns one segment (and one block of at most 64 columns: deltas and z-norm
-// are per column).  A wave streams its chunks through its own LDS region with the
-// (order - 1) x delwin halo rows on either side -- row indices clamped at the utterance's ends
-// exactly as Regress clamps its pointers -- and needs wave-level synchronisation only.
-//   k_seg_sums    every order's column sums (double) of a segment -> one partial vector per segment
+// utterances of any length, ragged batches included, and of the frame-range shards of one long
+// recording.  The static-feature kernel writes its rows compactly (numFrames x vSize) into a
+// plan-owned buffer.  Every utterance is cut into segments of 16 chunks of rows, at multiples of the
+// segment length from the utterance's own first row; one workgroup of four waves owns one segment
+// (and one block of at most 64 columns: deltas and z-norm are per column).  A wave works through
+// its chunks with the (order - 1) x delwin halo rows on either side -- row indices clamped at the
+// utterance's ends exactly as Regress clamps its pointers -- and needs wave-level synchronisation only.
+//   k_seg_pass / k_seg_reg, sums mode   every order's column sums (double) of a segment -> one
+//                 partial vector per segment
 //   k_seg_stats   an utterance's partial vectors added in a fixed order -> mean and 1 / std per column
-//   k_seg_write   the same chunks again: deltas formed once more, rows normalised, every output
-//                 row written once
-// Without z-norm only k_seg_write runs.  The statics are read twice, the output is written once,
+//                 (k_seg_shard_sums: a shard's raw sums for the exchange; k_totals_to_stats: mean and
+//                 1 / std from the recording's exchanged totals)
+//   k_seg_pass / k_seg_reg, write mode  the same chunks again: deltas formed once more, rows
+//                 normalised, every output row written once
+// Without z-norm only the write mode runs.  The statics are read twice, the output is written once,
 // nothing else touches HBM.  The partition of an utterance's rows into segments, chunks and lanes --
 // and with it the order in which its sums are added -- depends on the utterance and the option set
 // alone, never on its batch neighbours: a file comes out bit for bit the same alone and in any
