@@ -101,7 +101,7 @@ struct MFCCPlan {
     size_t finLds = 0;
     int mode = 0; // kernel mode: 0 general, 1 lean, 2 lean + matrix-core mel
     bool lean256 = false; // mode 2 run by the pipelined 256-point kernel
-    bool wide1024 = false; // 24-bit stereo, 1024 complex points: run by k_wide1024 (raw PCM bytes in LDS)
+    bool wide1024 = false; // 24-bit stereo, 1024 complex points: run by k_wide1024
     int pipe64 = 0;        // double precision, run by k_pipe64: 8 (mono 16-bit, 256 complex points) or 10 (24-bit stereo, 1024)
     int leanWaves = 0;    // ... with this many waves per workgroup
     int leanChunk = 0;    // ... tiles per chunk override (0: heuristic, -1: fixed ranges)
@@ -854,13 +854,14 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
         return MFCC_OK;
     }
     if (wideCand) {
-        // a wave's LDS region: the frame's raw bytes, one work area, the frame's log-mel rows
-        const int rawEl = wide1024_raw_bytes(c->cfg.wlen) / 4;
+        // a wave's LDS region: one work area, the frame's log-mel rows; shared: window pairs and
+        // the lanes' mel part tables
         const int workEl = 2 * (nc + nc / 16); // the padded complex points; every later use of the area is smaller
         const int P4 = (P + 3) & ~3;
         const int fbkL = c->cfg.fbankFlag ? 0 : V * P4; // log-mel values [channel][row], channels padded to 4
-        const int teamL = rawEl + workEl + fbkL + 4; // (+ the one point the split reads past the work area)
-        size_t bytes = (size_t)wide1024_waves() * teamL * sizeof(float);
+        const int teamL = workEl + fbkL + 4; // (+ the one point the split reads past the work area)
+        const int sharedL = wide1024_shared_elems(c->cfg.wlen);
+        size_t bytes = ((size_t)wide1024_waves() * teamL + sharedL) * sizeof(float);
         if (bytes > kLds) return choose_tile(p, false);
         // the cepstral table shares the LDS when there is room: rows zero-padded to 4 channels, odd pitch
         size_t dctL = 0;
@@ -873,12 +874,12 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
         if (dctLds) bytes += dctL * sizeof(float);
         p->wide1024 = true;
         p->framesPerTile = 1;
-        p->rowPitch = rawEl;
+        p->rowPitch = (int)dctL; // (this kernel: elements of the cepstral table's LDS copy)
         p->rawOrZElems = workEl;
         p->fbkElems = fbkL;
         p->featElems = 0;
         p->teamElems = teamL;
-        p->tabElems = dctLds ? (int)dctL : 0;
+        p->tabElems = sharedL + (int)dctL;
         p->tabPitch = dctPitchL;
         p->activeTeams = wide1024_waves();
         p->ldsBytes = bytes;
@@ -995,7 +996,8 @@ static int finish_plan(MFCCPlan *p)
                 // leave the planned bytes
                 const int64_t src = d.byteOff + first * bpi;
                 const int64_t vecs = (((int64_t)(nf - 1) * c->cfg.inc + c->cfg.wlen + 1) * bpi + 15) / 16;
-                const bool edge = src - bpi < 0 || src - bpi + vecs * 16 > planEnd;
+                const bool edge = p->wide1024 ? src - 8 < 0 || src + wide1024_reach_bytes(c->cfg.wlen) > planEnd
+                                              : src - bpi < 0 || src - bpi + vecs * 16 > planEnd;
                 if ((uint64_t)src > kTileOffMask) return set_error("PCM buffer larger than 2^48 bytes"), MFCC_E_ARG;
                 td.src = (uint64_t)src | ((uint64_t)nf << 48) | ((uint64_t)(first > 0 ? 0 : 1) << 60) | ((uint64_t)(edge ? 1 : 0) << 61);
                 td.outRow = d.outRow + f0;

@@ -188,10 +188,11 @@ int lean256_nz(int wlen);                 // first-stage inputs per lane that ca
 int lean256_waves(int wlen, bool fits12); // waves (teams) per workgroup
 int lean256_mel_steps(int melSteps);      // rows of the mel weight table the kernel keeps in LDS
 int launch_lean256(const FrontArgs<float> &a, int numBlocks, size_t ldsBytes, int waves, void *stream);
-// wide1024.hip: 24-bit stereo, 1024 complex points, raw PCM bytes in LDS
+// wide1024.hip: 24-bit stereo, 1024 complex points, samples expanded straight from the PCM bytes in memory
 bool wide1024_applies(int log2nc, int channels, int bps, int wlen);
 int wide1024_waves();
-int wide1024_raw_bytes(int wlen);         // LDS bytes a wave reserves for a frame's raw PCM
+int wide1024_shared_elems(int wlen);      // LDS elements the waves share in front of the cepstral table
+int wide1024_reach_bytes(int wlen);       // bytes from a frame's first instant that its loads reach
 int launch_wide1024(const FrontArgs<float> &a, int numBlocks, size_t ldsBytes, void *stream);
 // pipe64.hip: double precision, mono 16-bit with 256 complex points or 24-bit stereo with 1024
 int pipe64_class(int log2nc, int channels, int bps, int wlen, int inc); // 0: not taken, else 8 or 10

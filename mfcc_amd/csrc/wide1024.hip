@@ -27,15 +27,16 @@ namespace mfcc {
 
 namespace {
 
-constexpr int kWideLog2Nc = 10, kWideNc = 1024, kWideG = 64, kWidePpl = 16, kWideWaves = 8, kWidePfn = 11;
-constexpr int kWideBpi = 6; // bytes per instant: two channels of three bytes
+constexpr int kWideLog2Nc = 10, kWideNc = 1024, kWideG = 64, kWidePpl = 16, kWideWaves = 12;
 
-typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
+typedef unsigned int u3u __attribute__((ext_vector_type(3), aligned(1)));
+typedef unsigned int u2u __attribute__((ext_vector_type(2), aligned(1)));
 typedef unsigned int u4s __attribute__((ext_vector_type(4)));
 
 // One tile (frame) as the pipeline sees it: the two 64-bit words of its TileDesc (lean encoding:
-// byte offset of the frame's first instant, bit 60: it starts the signal, bit 61: a vector of its
-// fetch would leave the planned bytes; frames field 1, or 0 for "no tile").
+// byte offset of the frame's first instant, bit 60: it starts the signal, bit 61: a load of the
+// frame's bytes or of the 8 bytes in front of them would leave the planned bytes; frames field 1,
+// or 0 for "no tile").
 struct WideTile {
     unsigned w0, w1;
     int outRow;
@@ -67,6 +68,13 @@ __device__ __forceinline__ float wave_shl1f(float x, float last)
                                                                  0xf, 0xf, false));
 }
 
+// lane i takes x of lane i - 1; lane 0 takes `first`
+__device__ __forceinline__ float wave_shr1f(float x, float first)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, x), 0x138,
+                                                                 0xf, 0xf, false));
+}
+
 // 24-bit little-endian sample at byte O of the lane's window of NW dwords
 template <int O, int NW>
 __device__ __forceinline__ int sample24(const unsigned (&d)[NW])
@@ -75,65 +83,68 @@ __device__ __forceinline__ int sample24(const unsigned (&d)[NW])
 }
 
 
-// The lane's sample pairs (2n, 2n+1), n = l + 64 r, of derived row ROW (0 L, 1 R, 2 mid = 0.5 (L+R),
-// 3 side = L - R; main.c:198-207) from the frame's raw bytes: instants 2n-1 (the predecessor), 2n,
-// 2n+1 of both channels are 18 bytes from byte 12 n on.  Pre-emphasis over the whole signal
-// (PreEmphasise main.c:208, first-sample rule for the signal's first sample), Hamming window
-// (main.c:229); with ZC the zero crossings of the un-windowed samples (main.c:227), the samples
-// being formed in double with separately rounded product and difference as the reference's code
-// does, so that the sign of a near-cancelling sample is the reference's.
-template <int NZ, bool ZC, int ROW, bool EXACT>
-__device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, const unsigned *rawLane, int l,
-                                            const cpx<float> (&wreg)[NZ], double preK, float kf, float zcThr, bool firstTile, int wlen)
+// Sample of derived row ROW (0 L, 1 R, 2 mid = 0.5 (L+R), 3 side = L - R; main.c:198-207) from NW
+// dwords that hold the instant's two channels from byte O on.
+template <int ROW, int O, int NW>
+__device__ __forceinline__ float row_sample(const unsigned (&d)[NW])
+{
+    if constexpr (ROW == 0) return (float)sample24<O, NW>(d);
+    else if constexpr (ROW == 1) return (float)sample24<O + 3, NW>(d);
+    else if constexpr (ROW == 2) return 0.5f * (float)(sample24<O, NW>(d) + sample24<O + 3, NW>(d)); // (the integer sum is exact)
+    else return (float)(sample24<O, NW>(d) - sample24<O + 3, NW>(d));
+}
+
+// The lane's samples of row ROW from the frame's raw bytes: own[r] = the 12 bytes of instants 2n
+// and 2n+1, n = l + 64 r (both channels) -> xa[r], xb[r]; pred = the 8 bytes in front of the
+// frame's first instant (its predecessor: bytes 2 .. 7) -> pred0.
+template <int NZ, int ROW>
+__device__ __forceinline__ void wide_samples(float (&xa)[NZ], float (&xb)[NZ], float &pred0, const unsigned (&own)[NZ][3],
+                                             const unsigned (&pred)[2])
+{
+#pragma unroll
+    for (int r = 0; r < NZ; ++r) {
+        xa[r] = row_sample<ROW, 0, 3>(own[r]);
+        xb[r] = row_sample<ROW, 6, 3>(own[r]);
+    }
+    pred0 = row_sample<ROW, 2, 2>(pred);
+}
+
+// The lane's points (2n, 2n+1), n = l + 64 r, of the frame's row from its samples xa[r] = x[2n],
+// xb[r] = x[2n+1]; pred0 = the sample in front of the frame.  The predecessor 2n-1 of a pair is
+// the second sample of the previous lane's pair (of lane 63's previous pair for lane 0): one lane
+// shift.  Pre-emphasis over the whole signal (PreEmphasise main.c:208, first-sample rule for the
+// signal's first sample), Hamming window (main.c:229, pairs from winL); with ZC the zero crossings
+// of the un-windowed samples (main.c:227), whose signs must be those of the reference's double
+// arithmetic with separately rounded product and difference: the single-precision x1 - kf x0 (one
+// rounding, inputs exact) has that sign whenever it is not tiny against x0 -- the two differ by
+// (kf - k) x0 and the product's rounding, and zcThr is four times that bound.  Returns whether
+// some sample of the lane is that close to zero; the caller then counts the frame's crossings
+// again with wide_zc_exact.
+template <int NZ, bool ZC>
+__device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, const float (&xa)[NZ], const float (&xb)[NZ], float pred0,
+                                            int l, const cpx<float> *winL, double preK, float kf, float zcThr, bool firstTile, int wlen)
 {
     constexpr int G = kWideG;
     float nextFirst0 = 0; // sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r)
-    float margin = 1.0f;  // least |y| - zcThr |predecessor| over the lane's samples (EXACT off)
-    // All reads first, then the arithmetic.
-    unsigned own[NZ][5];
+    float margin = 1.0f;  // least |y| - zcThr |predecessor| over the lane's samples
+    cpx<float> wreg[NZ];
 #pragma unroll
-    for (int r = 0; r < NZ; ++r) {
-        const unsigned *src = rawLane + 3 * G * r; // (rawLane: the lane's first pair, raw + 3 l)
-        // (one 16-byte and one 4-byte read at a dword-aligned address: immediate offsets, no address arithmetic)
-        const u4u q = *reinterpret_cast<const u4u *>(src);
-        own[r][0] = q.x, own[r][1] = q.y, own[r][2] = q.z, own[r][3] = q.w;
-        own[r][4] = src[4];
-    }
+    for (int r = 0; r < NZ; ++r) wreg[r] = winL[l + G * r];
 #pragma unroll
     for (int r = NZ - 1; r >= 0; --r) {
-        const unsigned(&d)[5] = own[r];
-        int c[3];
-        if constexpr (ROW == 0) {
-            c[0] = sample24<0, 5>(d), c[1] = sample24<6, 5>(d), c[2] = sample24<12, 5>(d);
-        } else if constexpr (ROW == 1) {
-            c[0] = sample24<3, 5>(d), c[1] = sample24<9, 5>(d), c[2] = sample24<15, 5>(d);
-        } else if constexpr (ROW == 2) { // L + R, halved below (the integer sum is exact)
-            c[0] = sample24<0, 5>(d) + sample24<3, 5>(d), c[1] = sample24<6, 5>(d) + sample24<9, 5>(d);
-            c[2] = sample24<12, 5>(d) + sample24<15, 5>(d);
-        } else {
-            c[0] = sample24<0, 5>(d) - sample24<3, 5>(d), c[1] = sample24<6, 5>(d) - sample24<9, 5>(d);
-            c[2] = sample24<12, 5>(d) - sample24<15, 5>(d);
-        }
+        float x[3];
+        float carry = pred0;
+        if (r > 0) carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xb[r - 1]), 63));
+        x[0] = wave_shr1f(xb[r], carry);
+        x[1] = xa[r];
+        x[2] = xb[r];
         float y1, y2;
         if constexpr (ZC) {
-            // The crossings need the sign of the reference's double-precision sample x1 - rnd(k x0).
-            // The single-precision x1 - kf x0 (one rounding, inputs exact) has that sign whenever it
-            // is not tiny against x0: the two differ by (kf - k) x0 and the product's rounding, and
-            // zcThr is four times that bound.  A frame in which some sample is that close to zero
-            // is expanded again with EXACT, in double as the reference's code does it.
-            float x[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) x[i] = ROW == 2 ? 0.5f * (float)c[i] : (float)c[i];
-            if constexpr (EXACT) {
-                y1 = (float)sub_mul_exact((double)x[1], (double)x[0], preK);
-                y2 = (float)sub_mul_exact((double)x[2], (double)x[1], preK);
-            } else {
-                y1 = __builtin_fmaf(-kf, x[0], x[1]);
-                y2 = __builtin_fmaf(-kf, x[1], x[2]);
-                // (a zero sample after a zero predecessor is exact: margin 0, not below it)
-                margin = __builtin_fminf(margin, __builtin_fminf(__builtin_fmaf(-zcThr, __builtin_fabsf(x[0]), __builtin_fabsf(y1)),
-                                                                 __builtin_fmaf(-zcThr, __builtin_fabsf(x[1]), __builtin_fabsf(y2))));
-            }
+            y1 = __builtin_fmaf(-kf, x[0], x[1]);
+            y2 = __builtin_fmaf(-kf, x[1], x[2]);
+            // (a zero sample after a zero predecessor is exact: margin 0, not below it)
+            margin = __builtin_fminf(margin, __builtin_fminf(__builtin_fmaf(-zcThr, __builtin_fabsf(x[0]), __builtin_fabsf(y1)),
+                                                             __builtin_fmaf(-zcThr, __builtin_fabsf(x[1]), __builtin_fabsf(y2))));
             if (firstTile && l == 0 && r == 0) y1 = (float)((double)x[1] * (1.0 - preK)); // s[1] *= 1 - k
             // sample 2n+2 is the first sample of the next lane's pair (lane 63: of lane 0's next pair)
             const float x2 = wave_shl1f(y1, nextFirst0);
@@ -150,9 +161,6 @@ __device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, 
             zc += __builtin_popcountll(__builtin_amdgcn_ballot_w64(c01)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c12));
             nextFirst0 = __builtin_bit_cast(float, sgpr(__builtin_bit_cast(int, y1)));
         } else {
-            float x[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) x[i] = ROW == 2 ? 0.5f * (float)c[i] : (float)c[i];
             y1 = x[1] - kf * x[0];
             y2 = x[2] - kf * x[1];
             if (firstTile && l == 0 && r == 0) y1 = (float)((double)x[1] * (1.0 - preK));
@@ -164,14 +172,54 @@ __device__ __forceinline__ bool wide_expand(cpx<float> (&v)[kWidePpl], int &zc, 
     return margin < 0.0f;
 }
 
+// The frame's zero crossings of row ROW (zeroCrossingRate main.c:227) in the reference's arithmetic:
+// samples in double with separately rounded product and difference (PreEmphasise main.c:208).  For
+// the rare frame with a sample too close to zero for single precision to know its sign; written
+// for size, not speed: one sample pair per step, every byte read on its own and only inside the
+// buffer.  The count over the wave, the same in every lane.
+template <int ROW>
+__device__ __noinline__ int wide_zc_exact(const unsigned char *pcm, long long src, long long planEnd, int l, int nz, double preK,
+                                          bool firstTile, int wlen)
+{
+    int zc = 0;
+#pragma unroll 1
+    for (int r = 0; r < nz; ++r) {
+        const int s0 = 2 * (l + kWideG * r);
+        double x[4]; // instants s0 - 1 .. s0 + 2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long at = src + (long long)(s0 - 1 + i) * 6;
+            int c[2] = {0, 0};
+            if (at >= 0 && at + 6 <= planEnd) {
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const unsigned b0 = pcm[at + 3 * ch], b1 = pcm[at + 3 * ch + 1], b2 = pcm[at + 3 * ch + 2];
+                    c[ch] = ((int)((b0 | (b1 << 8) | (b2 << 16)) << 8)) >> 8;
+                }
+            }
+            x[i] = ROW == 0 ? (double)c[0] : ROW == 1 ? (double)c[1] : ROW == 2 ? 0.5 * (double)(c[0] + c[1]) : (double)(c[0] - c[1]);
+        }
+        double y1 = sub_mul_exact(x[1], x[0], preK);
+        const double y2 = sub_mul_exact(x[2], x[1], preK), y3 = sub_mul_exact(x[3], x[2], preK);
+        if (firstTile && s0 == 0) y1 = x[1] * (1.0 - preK); // s[1] *= 1 - k
+        const bool c01 = y1 * y2 < 0.0 && s0 + 1 < wlen, c12 = y2 * y3 < 0.0 && s0 + 2 < wlen;
+        zc += __builtin_popcountll(__builtin_amdgcn_ballot_w64(c01)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c12));
+    }
+    return zc;
+}
+
 // 1024-point complex FFT of the lane's 16 points v[r] = z[l + 64 r] into the work area Z (natural
-// order, padded): Stockham stages of radix 16, 16 and 4 as fft_stages makes them; twB / twC: the
-// lane's twiddle factors of the second and third stage.
-__device__ __forceinline__ void wide_fft(cpx<float> (&v)[kWidePpl], cpx<float> *Z, int l, const cpx<float> (&twB)[15],
-                                         const cpx<float> (&twC)[12])
+// order, padded): Stockham stages of radix 16, 16 and 4 as fft_stages makes them.  twt: the
+// twiddle table ([r-1][l mod 16] for the second stage, [r-1][l + 64 b] behind it for the third);
+// a stage's factors are requested while the stage before it runs and exchanges, so that they
+// occupy registers for one stage only.
+__device__ __forceinline__ void wide_fft(cpx<float> (&v)[kWidePpl], cpx<float> *Z, int l, const cpx<float> *twt, const unsigned lu)
 {
     typedef float T;
     constexpr int G = kWideG;
+    cpx<T> twB[15];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) twB[r - 1] = (twt + (r - 1) * 16)[lu & 15u]; // sub-transform size 16: [r-1][l mod 16]
     Radix<T, 16>::run(v);
 #pragma unroll
     for (int r = 0; r < 16; ++r) Z[zpad(16 * l + r)] = v[r];
@@ -180,6 +228,11 @@ __device__ __forceinline__ void wide_fft(cpx<float> (&v)[kWidePpl], cpx<float> *
 #pragma unroll
     for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], twB[r - 1]);
     group_sync<G>(); // every read of Z is done before any lane overwrites it
+    cpx<T> twC[12];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 1; r < 4; ++r) twC[b * 3 + r - 1] = (twt + (15 * 16 + (r - 1) * 256 + 64 * b))[lu]; // size 256: [r-1][l + 64 b]
     Radix<T, 16>::run(v);
     {
         const int o = ((l >> 4) << 8) + (l & 15);
@@ -243,8 +296,7 @@ template <int NZ, bool ZC>
 __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<float> a)
 {
     constexpr int NC = kWideNc, G = kWideG, PPL = kWidePpl, NPAIR = PPL / 2, TEAM = 64, WAVES = kWideWaves;
-    constexpr int PFN = kWidePfn, BPI = kWideBpi;
-    typedef float T;
+        typedef float T;
     STAMP_DECL
     STAMP_START;
     const int tid = threadIdx.x;
@@ -252,14 +304,17 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     const int tt0 = tid & 63;
     int tt = tt0, l = tt0;
 
-    // LDS, one region per wave: [raw PCM bytes of the frame | work area | log-mel rows of the frame]
+    // LDS: [window pairs | the lanes' mel part tables | cepstral table (when there is room; rows of
+    // P + 1 elements)] shared by the workgroup, then one region per wave: [work area | log-mel rows
+    // of the frame]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // (in front of them, when there is room: the cepstral table with rows of P + 1 elements)
-    T *dctL = reinterpret_cast<T *>(smem);
+    constexpr int kWinElems = 2 * G * NZ, kSegElems = 3 * 64 * 4;
+    cpx<T> *winL = reinterpret_cast<cpx<T> *>(smem);
+    int4 *segL = reinterpret_cast<int4 *>(smem + kWinElems * sizeof(T));
+    T *dctL = reinterpret_cast<T *>(smem) + kWinElems + kSegElems;
+    const bool dctInLds = a.rowPitch > 0; // (rowPitch: elements of the table's copy)
     unsigned char *region = smem + ((size_t)a.tabElems + (size_t)wave * a.teamElems) * sizeof(T);
-    unsigned *raw = reinterpret_cast<unsigned *>(region);
-    const unsigned *rawLane = raw + 3 * tt0; // the lane's first sample pair (plain lane index: kept over the rounds)
-    T *Zt = reinterpret_cast<T *>(region) + a.rowPitch; // (rowPitch: elements reserved for the raw bytes)
+    T *Zt = reinterpret_cast<T *>(region);
     cpx<T> *Z = reinterpret_cast<cpx<T> *>(Zt);
     cpx<T> *AB = Z;                                               // per bin (loWt p, p - loWt p)
     T *bandE = Zt + 2 * NC;                                       // sub-band sums (general band widths)
@@ -269,26 +324,23 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     if (!a.fbankFlag) {
         for (int i = tt0; i < ((a.P + 3) & ~3) * a.V; i += 64) fbkSep[i] = (T)0;
     }
-    if (a.tabElems > 0) {
+    for (int i = tid; i < G * NZ; i += WAVES * 64) winL[i] = reinterpret_cast<const cpx<T> *>(a.window)[i];
+    // mel segment parts of the lanes (round 0 and 1) and the part ranges of the lanes' channels
+    for (int i = tid; i < 3 * 64; i += WAVES * 64) segL[i] = reinterpret_cast<const int4 *>(a.laneSeg)[i];
+    if (dctInLds) {
         const int rows = a.M + a.c0Flag, pitch = a.tabPitch;
         for (int i = tid; i < rows * pitch; i += WAVES * 64) {
             const int j = i / pitch, k = i - j * pitch;
             dctL[i] = k < a.P ? a.dctT[j * a.dctPitch + k] : (T)0;
         }
-        __syncthreads();
     }
-    // Per-lane constants.  The window pairs stay in registers for the whole launch.  The twiddle
-    // factors of the second and third FFT stage and the split factors are read (through L1, the
-    // same few KB for every wave) before the round's first FFT stage, the filterbank weights after
-    // the split: each well before its use and before the round's result stores, so that waiting for
-    // a table never means waiting for stores issued just ahead of it.
-    cpx<T> wreg[NZ];
-#pragma unroll
-    for (int r = 0; r < NZ; ++r) wreg[r] = reinterpret_cast<const cpx<T> *>(a.window)[l + G * r];
+    __syncthreads();
+    // Tables.  The twiddle factors of the second and third FFT stage, the split factors and the
+    // filterbank weights are read through L1 (the same few KB for every wave), each well before its
+    // use, long after the previous round's result stores and before this round's: waiting for a
+    // table then never means waiting for stores issued just ahead of it.  What is needed at a
+    // round's very start -- the window pairs -- and the lanes' mel part tables come from LDS.
     const cpx<T> *twt = reinterpret_cast<const cpx<T> *>(a.tw), *splitTab = reinterpret_cast<const cpx<T> *>(a.splitTw);
-    // mel segment parts of the lane (round 0 and 1) and the part ranges of the lane's channel
-    const int4 *lseg = reinterpret_cast<const int4 *>(a.laneSeg);
-    const int4 part0 = lseg[l], part1 = lseg[64 + l], chanParts = lseg[128 + l];
     const float kf = (float)a.preK;
     const float zcThr = (float)(4.0 * __builtin_fabs((double)kf - a.preK)) + 1e-12f;
     const int JW = a.M + a.c0Flag;
@@ -350,57 +402,69 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     id = next_tile_s();
     WideTile nn = wide_desc(tab, id < 0 ? 0 : id, id >= 0);
 
-    const int tileBytes = (a.wlen + 1) * BPI;      // the frame's instants and the predecessor of the first
-    const int nvec = (tileBytes + 15) >> 4;
-    // Requests the raw bytes of tile t (vector j of lane tt = bytes 16 (tt + 64 j) .. + 15, byte 0
-    // being the first byte of the predecessor of the frame's first instant).  Tiles at the first or
-    // last bytes of the buffer keep every vector inside it by clamping its offset (store_raw then
-    // redoes such a tile byte by byte).
-    // (every vector is loaded, the ones behind the tile's last from the last one's place: the
-    // registers then have a single definition and are dead once stored)
-    auto fetch = [&](const WideTile &t, u4u (&pf)[PFN]) {
-        const long long off0 = t.src() - BPI;
-        int lo = 0, hi = 16 * (nvec - 1);
-        if (t.edge()) {
-            lo = (int)(off0 < 0 ? -off0 : 0);
-            hi = (int)min(a.planEnd - 16 - off0, (long long)hi);
-        }
-        const unsigned char *g = a.pcm + off0;
+    // The frame's raw bytes as the lanes need them, straight from memory: own[r] = the 12 bytes of
+    // the lane's sample pair n = tt + 64 r (a wave's load is 768 consecutive bytes), pred = the 8
+    // bytes in front of the frame's first instant.  A frame at the first or last bytes of the
+    // buffer (edge) keeps every load inside it: a load that would pass the end is moved back and
+    // its bytes are shifted into place (zeros behind the end; such bytes lie behind the frame's
+    // last sample), and the predecessor is read byte by byte.
+    auto load_raw = [&](const WideTile &t, unsigned (&own)[NZ][3], unsigned (&pred)[2]) {
+        const long long src = t.src();
+        const unsigned char *g = a.pcm + src;
+        if (!t.edge()) {
 #pragma unroll
-        for (int j = 0; j < PFN; ++j) pf[j] = *reinterpret_cast<const u4u *>(g + min(max(16 * (tt + j * TEAM), lo), hi));
-    };
-    auto store_raw = [&](const WideTile &t, const u4u (&pf)[PFN]) {
-#pragma unroll
-        for (int j = 0; j < PFN; ++j) {
-            const int vj = tt + j * TEAM;
-            if (vj < nvec) reinterpret_cast<uint4 *>(raw)[vj] = make_uint4(pf[j].x, pf[j].y, pf[j].z, pf[j].w);
-        }
-        if (t.edge()) {
-            const long long off0 = t.src() - BPI;
-            unsigned char *rb = reinterpret_cast<unsigned char *>(raw);
-            for (int b = tt; b < tileBytes; b += TEAM) {
-                const long long g = off0 + b;
-                rb[b] = (g >= 0 && g < a.planEnd) ? a.pcm[g] : (unsigned char)0;
+            for (int r = 0; r < NZ; ++r) {
+                const u3u q = *reinterpret_cast<const u3u *>(g + 12 * (tt + G * r));
+                own[r][0] = q.x, own[r][1] = q.y, own[r][2] = q.z;
             }
+            const u2u pq = *reinterpret_cast<const u2u *>(g - 8);
+            pred[0] = pq.x, pred[1] = pq.y;
+        } else {
+            const int lim = (int)min(a.planEnd - src, (long long)(1 << 30)); // bytes of the buffer from the frame's first on
+#pragma unroll
+            for (int r = 0; r < NZ; ++r) {
+                const int at = 12 * (tt + G * r);
+                const int back = max(at - (lim - 12), 0); // bytes the load is moved back by
+                const u3u q = *reinterpret_cast<const u3u *>(g + (at - back));
+                const int words = back >> 2;
+                const unsigned e0 = words == 0 ? q.x : words == 1 ? q.y : words == 2 ? q.z : 0u;
+                const unsigned e1 = words == 0 ? q.y : words == 1 ? q.z : 0u;
+                const unsigned e2 = words == 0 ? q.z : 0u;
+                own[r][0] = __builtin_amdgcn_alignbyte(e1, e0, (unsigned)back & 3u);
+                own[r][1] = __builtin_amdgcn_alignbyte(e2, e1, (unsigned)back & 3u);
+                own[r][2] = __builtin_amdgcn_alignbyte(0u, e2, (unsigned)back & 3u);
+            }
+            unsigned pb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pb[i] = src - 8 + i >= 0 ? (unsigned)a.pcm[src - 8 + i] : 0u;
+            pred[0] = pb[0] | (pb[1] << 8) | (pb[2] << 16) | (pb[3] << 24);
+            pred[1] = pb[4] | (pb[5] << 8) | (pb[6] << 16) | (pb[7] << 24);
         }
     };
 
-    // Prologue: the first tile's bytes.
+    // The samples of the round to come, carried from round to round: a round asks for the next
+    // round's bytes once its spectrum has been reduced to per-bin values, and turns them into that
+    // row's samples just before its own results go out, so that no round starts by waiting for
+    // memory behind the stores of the one before it.
+    float xa[NZ], xb[NZ], pred0;
+    auto to_samples = [&](const int row, const unsigned (&own)[NZ][3], const unsigned (&pred)[2]) {
+        switch (row) { // (the same for every lane)
+        case 0: wide_samples<NZ, 0>(xa, xb, pred0, own, pred); break;
+        case 1: wide_samples<NZ, 1>(xa, xb, pred0, own, pred); break;
+        case 2: wide_samples<NZ, 2>(xa, xb, pred0, own, pred); break;
+        default: wide_samples<NZ, 3>(xa, xb, pred0, own, pred); break;
+        }
+    };
     {
-        u4u pf0[PFN];
-        fetch(cur, pf0);
-        store_raw(cur, pf0);
-        team_sync<TEAM>();
+        unsigned own[NZ][3], pred[2];
+        load_raw(cur, own, pred);
+        to_samples(0, own, pred);
     }
 
-    // One (frame, row) round.  The frame's last row (LAST) asks for the next frame's bytes once its
-    // spectrum is in registers and stores them over this frame's before its own results go out, so
-    // that the registers carrying them are live inside that round only and the wait for them does
-    // not include the round's result stores.
+    // One (frame, row) round (LAST: the frame's last row, which also forms the cepstra).
     WideTile d3 = {0u, 0u, 0};
     auto round = [&](const int vv, auto lastTag) {
         constexpr bool LAST = decltype(lastTag)::value;
-        u4u pf[LAST ? PFN : 1];
         // (the lane index is made opaque once per round: what derives from it -- addresses, bin
         // weights, masks -- is then recomputed here in a few instructions instead of being kept in
         // registers, or spilled, across the whole loop)
@@ -411,27 +475,20 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
         {
             STAMP(0);
             float *fo = outRow + vv * a.D;
-            // ---- the lane's sample pairs (2n, 2n+1), n = l + 64 r, of derived row vv from the raw
-            //      bytes: instants 2n-1 (predecessor), 2n, 2n+1 of both channels are 18 bytes from
-            //      byte 12 n on; rows main.c:198-207, PreEmphasise main.c:208 (first-sample rule for
-            //      the signal's first sample), Ham main.c:229, te mfcc.c:138-142
+            // ---- the lane's points (2n, 2n+1), n = l + 64 r, of derived row vv from its samples
+            //      (rows main.c:198-207): PreEmphasise main.c:208 (first-sample rule for the signal's
+            //      first sample), Ham main.c:229, te mfcc.c:138-142
             cpx<T> v[PPL];
             int zc = 0;
-            bool unsure;
-            switch (vv) { // (the same for every lane)
-            case 0: unsure = wide_expand<NZ, ZC, 0, false>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-            case 1: unsure = wide_expand<NZ, ZC, 1, false>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-            case 2: unsure = wide_expand<NZ, ZC, 2, false>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-            default: unsure = wide_expand<NZ, ZC, 3, false>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-            }
+            const bool unsure = wide_expand<NZ, ZC>(v, zc, xa, xb, pred0, l, winL, a.preK, kf, zcThr, firstTile, a.wlen);
             if constexpr (ZC) {
                 if (__builtin_amdgcn_ballot_w64(unsure) != 0ull) {
-                    zc = 0;
+                    const long long src = cur.src();
                     switch (vv) {
-                    case 0: wide_expand<NZ, ZC, 0, true>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-                    case 1: wide_expand<NZ, ZC, 1, true>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-                    case 2: wide_expand<NZ, ZC, 2, true>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
-                    default: wide_expand<NZ, ZC, 3, true>(v, zc, rawLane, l, wreg, a.preK, kf, zcThr, firstTile, a.wlen); break;
+                    case 0: zc = wide_zc_exact<0>(a.pcm, src, a.planEnd, l, NZ, a.preK, firstTile, a.wlen); break;
+                    case 1: zc = wide_zc_exact<1>(a.pcm, src, a.planEnd, l, NZ, a.preK, firstTile, a.wlen); break;
+                    case 2: zc = wide_zc_exact<2>(a.pcm, src, a.planEnd, l, NZ, a.preK, firstTile, a.wlen); break;
+                    default: zc = wide_zc_exact<3>(a.pcm, src, a.planEnd, l, NZ, a.preK, firstTile, a.wlen); break;
                     }
                 }
             }
@@ -443,20 +500,14 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                 te = group_sum<T, G>((T)4 * (e2.x + e2.y), nullptr, tt); // (half-scaled window)
             }
             STAMP(1);
-            cpx<T> twB[15], twC[12], swreg[NPAIR];
-            const unsigned lu = (unsigned)tt0; // (one unsigned lane offset under uniform row pointers: scalar address arithmetic)
-#pragma unroll
-            for (int r = 1; r < 16; ++r) twB[r - 1] = (twt + (r - 1) * 16)[lu & 15u]; // sub-transform size 16: [r-1][l mod 16]
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 1; r < 4; ++r) twC[b * 3 + r - 1] = (twt + (15 * 16 + (r - 1) * 256 + 64 * b))[lu]; // size 256: [r-1][l + 64 b]
-#pragma unroll
-            for (int q = 0; q < NPAIR; ++q) swreg[q] = (splitTab + G * q)[lu];
+            const unsigned lu = (unsigned)tt; // (one unsigned lane offset under uniform row pointers: scalar address arithmetic)
             STAMP(2);
 
             // ---- 1024-point complex FFT of z[n] = x[2n] + i x[2n+1] (Realft mfcc.c:262-270)
-            wide_fft(v, Z, tt0, twB, twC); // (plain lane index: the stage addresses stay in registers over the rounds)
+            wide_fft(v, Z, tt, twt, lu);
+            cpx<T> swreg[NPAIR];
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) swreg[q] = (splitTab + G * q)[lu];
             STAMP(3);
 
             // ---- real-FFT split and power (mfcc.c:274-290, ek of mfcc.c:153-155)
@@ -464,8 +515,8 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             {
                 constexpr int QS = (G + G / 16) * 8;
                 cpx<T> zas[NPAIR], rev[NPAIR];
-                lds_read_strided<NPAIR, QS>(zas, &Z[zpad(tt0)]);
-                lds_read_strided<NPAIR, QS>(rev, &Z[zpad(NC - tt0 - G * (NPAIR - 1))]); // (lane 0: one point past the area, unused)
+                lds_read_strided<NPAIR, QS>(zas, &Z[zpad(tt)]);
+                lds_read_strided<NPAIR, QS>(rev, &Z[zpad(NC - tt - G * (NPAIR - 1))]); // (lane 0: one point past the area, unused)
 #pragma unroll
                 for (int q = 0; q < NPAIR; ++q) split_power<T>(zas[q], rev[NPAIR - 1 - q], swreg[q], pa[q], pb[q]);
                 // bin 0 packs Re + Im of Z[0] (mfcc.c:288-290); bin nc/2 is |Z[nc/2]|^2
@@ -501,6 +552,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             // ---- sub-band energies / brightness (main.c:235-236): from the registers when a band is a
             //      whole number of 64-bin strides, else from the plain power values in the work area
             const bool bandsFromRegs = F_S == 2 || F_S == 4 || F_S == 8 || F_S == 16;
+            T bandOut = 0, brightOut = 0; // (stored with the round's other results, at its end)
             if (bandsFromRegs) {
                 float e[16], ek[16];
 #pragma unroll
@@ -536,9 +588,8 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                 // i.e. over lanes 0 .. S-1 of a row of 16
                 const T totals = group_sum<T, 16>((l & 15) < F_S ? tot : (T)0, nullptr, tt);
                 const T num = __shfl(totals, 16, 64);
-                const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
-                if (l < F_S) fo[subAt + l] = tot / totals;
-                if (l == 0 && a.brightFlag) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = num / totals / (T)NC;
+                bandOut = tot / totals;
+                brightOut = num / totals / (T)NC;
             } else if (F_S > 0) {
 #pragma unroll
                 for (int q = 0; q < NPAIR; ++q) {
@@ -584,18 +635,17 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                     for (int g = 0; g < nseg; ++g) fo[subAt + g] = bandE[g] / total;
                 }
             }
-            if (l == 0) {
-                if (F_S == 0 && a.brightFlag) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = regNum / regTotal / (T)NC;
-                if (a.energyFlag) fo[a.M + a.c0Flag] = tlog<T>(te);                               // main.c:243
-                if (ZC) fo[a.M + a.c0Flag + a.energyFlag] = (T)zc / (T)(a.wlen - 1);              // main.c:244
-            }
+            if (F_S == 0 && a.brightFlag) brightOut = regNum / regTotal / (T)NC;
+            const T teOut = a.energyFlag ? tlog<T>(te) : (T)0;
 
             STAMP(7);
+            // ---- the bytes of the round to come (this frame's next row, or the next frame's first)
+            unsigned own[NZ][3], pred[2];
             if constexpr (LAST) {
-                if (nx.valid()) {
-                    draw_step();
-                    fetch(nx, pf);
-                }
+                if (nx.valid()) draw_step();
+                load_raw(nx.valid() ? nx : cur, own, pred); // (behind the last frame: this one's again, unused)
+            } else {
+                load_raw(cur, own, pred);
             }
             // ---- per bin, exactly the two products of mfcc.c:160-162: t1 = loWt ek and ek - t1
 #pragma unroll
@@ -617,7 +667,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             cpx<T> ps[2];
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
-                const int4 sg = rd == 0 ? part0 : part1;
+                const int4 sg = segL[64 * rd + l];
                 cpx<T> acc = {0, 0};
                 if (rd < a.maxSeg) {
                     for (int h = 0; h < a.melPieces; ++h) { // melPieces x 8 bins per part at most
@@ -637,18 +687,22 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             }
             STAMP(8);
             group_sync<G>(); // every part has been read: the pairs' place takes the part sums
-            if (part0.z >= 0) {
-                Pw[part0.z] = ps[0].x;
-                Pw[128 + part0.z] = ps[0].y;
-            }
-            if (a.maxSeg > 1 && part1.z >= 0) {
-                Pw[part1.z] = ps[1].x;
-                Pw[128 + part1.z] = ps[1].y;
+            {
+                const int slot0 = segL[l].z, slot1 = segL[64 + l].z;
+                if (slot0 >= 0) {
+                    Pw[slot0] = ps[0].x;
+                    Pw[128 + slot0] = ps[0].y;
+                }
+                if (a.maxSeg > 1 && slot1 >= 0) {
+                    Pw[slot1] = ps[1].x;
+                    Pw[128 + slot1] = ps[1].y;
+                }
             }
             group_sync<G>();
             T lv = 0;
             if (l < a.P) {
                 // (at most 10 parts per segment: all reads go out together, the sums stay in part order)
+                const int4 chanParts = segL[128 + l];
                 T pu[10], pt[10];
 #pragma unroll
                 for (int j = 0; j < 10; ++j) {
@@ -665,16 +719,21 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                 const T m = mu + mt;
                 lv = tlog<T>(m < (T)1 ? (T)1 : m);
             }
-            if constexpr (LAST) {
-                // every row of the frame has expanded its samples (the FFT's exchanges lie between):
-                // the next frame's bytes take their place
-                if (nx.valid()) store_raw(nx, pf);
+            to_samples(LAST ? 0 : vv + 1, own, pred);
+            // ---- the round's results (row layout main.c:241-249)
+            if (bandsFromRegs) {
+                if (l < F_S) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag + l] = bandOut;
+            }
+            if (l == 0) {
+                if (a.brightFlag && (bandsFromRegs || F_S == 0)) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = brightOut;
+                if (a.energyFlag) fo[a.M + a.c0Flag] = teOut;                                     // main.c:243
+                if (ZC) fo[a.M + a.c0Flag + a.energyFlag] = (T)zc / (T)(a.wlen - 1);              // main.c:244
             }
             if (l < a.P) {
                 if (a.fbankFlag) fo[l] = lv;
                 else fbkSep[l * F_V + vv] = lv; // [channel][row]
             }
-            team_sync<TEAM>(); // the work area is free for the next round, the raw bytes are in place
+            team_sync<TEAM>(); // the work area is free for the next round
             STAMP(6);
         }
         if (LAST && !a.fbankFlag) {
@@ -720,7 +779,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                 default: cepstra(std::integral_constant<int, 4>{}, paddedTag, table, pitch); break;
                 }
             };
-            if (a.tabElems > 0) cepstra_rows(std::true_type{}, dctL, a.tabPitch);
+            if (dctInLds) cepstra_rows(std::true_type{}, dctL, a.tabPitch);
             else cepstra_rows(std::false_type{}, a.dctT, a.dctPitch);
             team_sync<TEAM>();
         }
@@ -744,13 +803,14 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
 // Geometry the host plans with.
 int wide1024_nz(int wlen) { return (wlen + 127) / 128; }
 int wide1024_waves() { return kWideWaves; }
-int wide1024_raw_bytes(int wlen) { return ((((wlen + 1) * kWideBpi + 15) >> 4) << 4); }
+// elements of the LDS part the waves share in front of the cepstral table: window pairs, mel part tables
+int wide1024_shared_elems(int wlen) { return 2 * 64 * (wide1024_nz(wlen) == 14 ? 14 : 16) + 3 * 64 * 4; }
+// bytes from a frame's first instant that the kernel's loads reach (12 per sample pair, 64 x NZ pairs)
+int wide1024_reach_bytes(int wlen) { return 12 * 64 * (wide1024_nz(wlen) == 14 ? 14 : 16); }
 
 bool wide1024_applies(int log2nc, int channels, int bps, int wlen)
 {
-    const int vecs = ((wlen + 1) * kWideBpi + 15) >> 4;
-    return log2nc == kWideLog2Nc && channels == 2 && bps == 3 && vecs <= kWidePfn * 64 && wide1024_nz(wlen) >= 9 &&
-           wide1024_nz(wlen) <= 16;
+    return log2nc == kWideLog2Nc && channels == 2 && bps == 3 && wide1024_nz(wlen) >= 9 && wide1024_nz(wlen) <= 16;
 }
 
 template <int NZ, bool ZC>
