@@ -586,7 +586,27 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
             while (lpb * 2 * nseg <= G) lpb *= 2;
             const int b = l / lpb, sl = l & (lpb - 1);
             T e = 0, ek = 0;
-            if (b < nseg) {
+            if (G == 64 && (nseg & (nseg - 1)) == 0) {
+                // Bands of a power-of-two width lie a multiple of the banks' span apart: the lanes of
+                // band b start lpb b bins into it and wrap around, so that the bands' simultaneous
+                // reads fall into different banks (the sums only change their order).
+                const int lo = b * width, rot = sl + lpb * b, steps = width / lpb; // (steps >= 16: nseg <= 8 here, else one lane per band)
+                for (int i0 = 0; i0 < steps; i0 += 8) {
+                    T pv[8];
+                    int kk[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        kk[i] = lo + ((rot + (i0 + i) * lpb) & (width - 1));
+                        pv[i] = Pw[kk[i]];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const bool in = i0 + i < steps;
+                        e += in ? pv[i] : (T)0;
+                        ek += in ? (T)(kk[i] + 1) * pv[i] : (T)0;
+                    }
+                }
+            } else if (b < nseg) {
                 const int lo = b * width, hi = (b == nseg - 1) ? NC : lo + width;
                 for (int k = lo + sl; k < hi; k += 4 * lpb) { // four reads in flight
                     T pv[4];

@@ -404,41 +404,48 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
 
     // The frame's raw bytes as the lanes need them, straight from memory: own[r] = the 12 bytes of
     // the lane's sample pair n = tt + 64 r (a wave's load is 768 consecutive bytes), pred = the 8
-    // bytes in front of the frame's first instant.  A frame at the first or last bytes of the
-    // buffer (edge) keeps every load inside it: a load that would pass the end is moved back and
-    // its bytes are shifted into place (zeros behind the end; such bytes lie behind the frame's
-    // last sample), and the predecessor is read byte by byte.
+    // bytes in front of the frame's first instant.  One path for every frame, so that the loaded
+    // registers have a single definition and nothing waits for them here: a frame at the last
+    // bytes of the buffer (edge) moves the loads that would pass the end back to it, one at its
+    // first bytes reads the predecessor from the buffer's start; fix_raw then shifts those bytes
+    // into place.  (Only pairs from kClampFrom on can lie behind the shortest frame's last byte.)
+    constexpr int kClampFrom = NZ == 14 ? 13 : 8;
     auto load_raw = [&](const WideTile &t, unsigned (&own)[NZ][3], unsigned (&pred)[2]) {
         const long long src = t.src();
         const unsigned char *g = a.pcm + src;
-        if (!t.edge()) {
+        const int lastAt = t.edge() ? (int)min(a.planEnd - src, (long long)(1 << 30)) - 12 : 0x7fffffff;
 #pragma unroll
-            for (int r = 0; r < NZ; ++r) {
-                const u3u q = *reinterpret_cast<const u3u *>(g + 12 * (tt + G * r));
-                own[r][0] = q.x, own[r][1] = q.y, own[r][2] = q.z;
-            }
-            const u2u pq = *reinterpret_cast<const u2u *>(g - 8);
-            pred[0] = pq.x, pred[1] = pq.y;
-        } else {
-            const int lim = (int)min(a.planEnd - src, (long long)(1 << 30)); // bytes of the buffer from the frame's first on
+        for (int r = 0; r < NZ; ++r) {
+            u3u q;
+            // (a uniform pointer per pair plus one unsigned lane offset: scalar address arithmetic)
+            if (r < kClampFrom) q = *reinterpret_cast<const u3u *>(g + 12 * G * r + 12u * (unsigned)tt);
+            else q = *reinterpret_cast<const u3u *>(g + min(12 * (tt + G * r), lastAt));
+            own[r][0] = q.x, own[r][1] = q.y, own[r][2] = q.z;
+        }
+        const u2u pq = *reinterpret_cast<const u2u *>(g - (src >= 8 ? 8 : src));
+        pred[0] = pq.x, pred[1] = pq.y;
+    };
+    auto fix_raw = [&](const WideTile &t, unsigned (&own)[NZ][3], unsigned (&pred)[2]) {
+        if (t.edge()) {
+            const long long src = t.src();
+            const int lastAt = (int)min(a.planEnd - src, (long long)(1 << 30)) - 12;
 #pragma unroll
-            for (int r = 0; r < NZ; ++r) {
-                const int at = 12 * (tt + G * r);
-                const int back = max(at - (lim - 12), 0); // bytes the load is moved back by
-                const u3u q = *reinterpret_cast<const u3u *>(g + (at - back));
+            for (int r = kClampFrom; r < NZ; ++r) {
+                const int back = max(12 * (tt + G * r) - lastAt, 0); // bytes the load was moved back by
                 const int words = back >> 2;
-                const unsigned e0 = words == 0 ? q.x : words == 1 ? q.y : words == 2 ? q.z : 0u;
-                const unsigned e1 = words == 0 ? q.y : words == 1 ? q.z : 0u;
-                const unsigned e2 = words == 0 ? q.z : 0u;
+                const unsigned q0 = own[r][0], q1 = own[r][1], q2 = own[r][2];
+                const unsigned e0 = words == 0 ? q0 : words == 1 ? q1 : words == 2 ? q2 : 0u;
+                const unsigned e1 = words == 0 ? q1 : words == 1 ? q2 : 0u;
+                const unsigned e2 = words == 0 ? q2 : 0u;
                 own[r][0] = __builtin_amdgcn_alignbyte(e1, e0, (unsigned)back & 3u);
                 own[r][1] = __builtin_amdgcn_alignbyte(e2, e1, (unsigned)back & 3u);
                 own[r][2] = __builtin_amdgcn_alignbyte(0u, e2, (unsigned)back & 3u);
             }
-            unsigned pb[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) pb[i] = src - 8 + i >= 0 ? (unsigned)a.pcm[src - 8 + i] : 0u;
-            pred[0] = pb[0] | (pb[1] << 8) | (pb[2] << 16) | (pb[3] << 24);
-            pred[1] = pb[4] | (pb[5] << 8) | (pb[6] << 16) | (pb[7] << 24);
+            if (src < 8) { // the 8 bytes were read from the buffer's start: its first `src` are the wanted last ones
+                const unsigned long long both = ((unsigned long long)pred[1] << 32) | pred[0];
+                const unsigned long long moved = src > 0 ? both << (8 * (8 - (int)src)) : 0ull;
+                pred[0] = (unsigned)moved, pred[1] = (unsigned)(moved >> 32);
+            }
         }
     };
 
@@ -458,6 +465,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     {
         unsigned own[NZ][3], pred[2];
         load_raw(cur, own, pred);
+        fix_raw(cur, own, pred);
         to_samples(0, own, pred);
     }
 
@@ -719,6 +727,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
                 const T m = mu + mt;
                 lv = tlog<T>(m < (T)1 ? (T)1 : m);
             }
+            fix_raw(LAST && nx.valid() ? nx : cur, own, pred);
             to_samples(LAST ? 0 : vv + 1, own, pred);
             // ---- the round's results (row layout main.c:241-249)
             if (bandsFromRegs) {

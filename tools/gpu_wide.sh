@@ -12,7 +12,7 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout
 fi
 tail -3 $out/pytest.log
 for w in c4 c5; do
-timeout -k 10 200 python3 bench.py --workload $w --precision f32 --no-other --steps 20 --warmup 3 --no-cpu --no-host > $out/bench_$w.json 2> $out/bench_$w.err
+timeout -k 10 200 python3 bench.py --workload $w --precision ${PREC:-f32} --no-other --steps 20 --warmup 3 --no-cpu --no-host > $out/bench_$w.json 2> $out/bench_$w.err
 python3 -c "
 import json,sys
 d=json.load(open('$out/bench_$w.json'))
