@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
         // weights, masks -- is then recomputed here in a few instructions instead of being kept in
         // registers, or spilled, across the whole loop)
         asm volatile("" : "+v"(tt));
-        l = tt;
+        l = tt & 63; // (says the range: l + 64 q is then known to be zero for q = 0 only)
         float *outRow = a.out + (long long)cur.outRow * a.step;
         const bool firstTile = cur.first();
         {

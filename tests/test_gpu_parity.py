@@ -179,6 +179,26 @@ def test_stereo_2048_point_kernel_modes(oracle, wlen, bank, vec, cepstral, extra
             _compare(g, ref, kw, f64)
 
 
+@pytest.mark.parametrize("wlen,inc", [(1025, 1), (1025, 342), (1765, 441), (2047, 700), (2048, 512), (1764, 882)])
+def test_stereo_frames_at_the_first_and_last_bytes_of_the_buffer(oracle, wlen, inc):
+    """The 24-bit stereo kernels read a frame's bytes straight from the buffer: a frame whose last
+    sample is the buffer's last (odd and even frame lengths: the last sample pair then lies half or
+    wholly behind the end), frames that start within the buffer's first 8 bytes (shift of one
+    sample), in both precisions, alone and behind a neighbour."""
+    kw = dict(sampleRate=44100, lowpassfre=-1, hipassfre=-1, preemphasise=0.97, wlen=wlen, inc=inc, vecNum=4,
+              fbankFlag=1, bankNum=24, MFCCNum=12, MFCC0thFlag=0, energyFlag=1, zeroCrossingFlag=1, brightFlag=1,
+              subBandEFlag=8)
+    ocfg = oracle.make_config(**kw)
+    for lens in ([wlen + 5 * inc], [wlen + 2 * inc + 3, wlen + 3 * inc], [wlen]):
+        pcms = [_pcm(n, 2, 3, wlen + i, 44100, tone=0) for i, n in enumerate(lens)]
+        refs = [oracle.extract_pcm_bytes(ocfg, p, 2, 3) for p in pcms]
+        for f64 in (False, True):
+            cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+            got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 2, 3, pad=0)
+            for g, ref in zip(got, refs):
+                _compare(g, ref, kw, f64)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MFCC_FUZZ_SEEDS", "48"))))
 def test_random_configurations(oracle, seed, tuning):
     """Seeded random walk over the option space (frame geometry, channel layouts, feature flags,
