@@ -833,24 +833,30 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
         const int teamL = rawEl + gt * pipe64_area_elems(pipeCls);
         p->melSteps = 0;
         if (!(pipeCls == 8 ? pipe64_mel_matrix(p, tune.debug != 0) : pipe64_part_table(p, pipeCls, tune.debug != 0))) return choose_tile(p, false);
-        const int tabL = pipe64_tab_elems(pipeCls, c->cfg.wlen, c->dctElems, p->melSteps);
-        const size_t bytes = ((size_t)tabL + (size_t)pipe64_waves() * teamL) * sizeof(double);
+        int tabL = pipe64_tab_elems(pipeCls, c->cfg.wlen, c->dctElems, p->melSteps);
+        size_t bytes = ((size_t)tabL + (size_t)pipe64_waves(pipeCls) * teamL) * sizeof(double);
         if (bytes > kLds) return choose_tile(p, false);
+        int dctLdsEl = 0; // 1024-point class: the cepstral table shares the LDS when there is room
+        if (pipeCls == 10 && c->dctElems > 0 && bytes + (((size_t)c->dctElems + 1) & ~(size_t)1) * sizeof(double) <= kLds) {
+            dctLdsEl = (c->dctElems + 1) & ~1;
+            tabL += dctLdsEl;
+            bytes += (size_t)dctLdsEl * sizeof(double);
+        }
         p->pipe64 = pipeCls;
         p->framesPerTile = gt;
-        p->rowPitch = rawEl;
+        p->rowPitch = pipeCls == 10 ? dctLdsEl : rawEl; // (1024-point class: elements of the table's LDS copy)
         p->rawOrZElems = gt * pipe64_area_elems(pipeCls);
         p->fbkElems = 0;
         p->featElems = 0;
         p->teamElems = teamL;
         p->tabElems = tabL;
-        p->activeTeams = pipe64_waves();
+        p->activeTeams = pipe64_waves(pipeCls);
         p->ldsBytes = bytes;
         p->blocksPerCu = 1;
         p->mode = 0;
         if (tune.debug)
             fprintf(stderr, "mfcc plan: double-precision pipelined kernel, %d complex points, %d waves per workgroup, LDS %zu B\n", 1 << pipeCls,
-                    pipe64_waves(), bytes);
+                    pipe64_waves(pipeCls), bytes);
         return MFCC_OK;
     }
     if (wideCand) {
@@ -996,8 +1002,9 @@ static int finish_plan(MFCCPlan *p)
                 // leave the planned bytes
                 const int64_t src = d.byteOff + first * bpi;
                 const int64_t vecs = (((int64_t)(nf - 1) * c->cfg.inc + c->cfg.wlen + 1) * bpi + 15) / 16;
-                const bool edge = p->wide1024 ? src - 8 < 0 || src + wide1024_reach_bytes(c->cfg.wlen) > planEnd
-                                              : src - bpi < 0 || src - bpi + vecs * 16 > planEnd;
+                const bool edge = p->wide1024      ? src - 8 < 0 || src + wide1024_reach_bytes(c->cfg.wlen) > planEnd
+                                  : p->pipe64 == 10 ? src - 8 < 0 || src + pipe64_reach_bytes(c->cfg.wlen) > planEnd
+                                                    : src - bpi < 0 || src - bpi + vecs * 16 > planEnd;
                 if ((uint64_t)src > kTileOffMask) return set_error("PCM buffer larger than 2^48 bytes"), MFCC_E_ARG;
                 td.src = (uint64_t)src | ((uint64_t)nf << 48) | ((uint64_t)(first > 0 ? 0 : 1) << 60) | ((uint64_t)(edge ? 1 : 0) << 61);
                 td.outRow = d.outRow + f0;

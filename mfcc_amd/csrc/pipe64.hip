@@ -819,6 +819,572 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
 }
 
 // ------------------------------------------------------------------------------------------
+// 1024-point class (24-bit stereo, frames of 1025 .. 2048 samples): one wave per frame, 64 lanes x
+// 16 points, twelve waves per workgroup (three per SIMD, 168 registers).  Nothing of a frame's raw
+// bytes is kept in LDS: a round asks for the next round's bytes straight from memory (one 12-byte
+// load per sample pair; a wave's load is 768 consecutive bytes) once its spectrum has been reduced
+// to per-bin values, turns them into that row's integer samples just before its own results go
+// out, and carries those to the next round -- so no round starts by waiting for memory behind the
+// stores of the one before it.  LDS: [filterbank weights | window pairs | the lanes' mel part
+// tables | cepstral table when there is room] shared, then one work area per wave.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kPipeWideWaves = 12;
+
+typedef unsigned int u3u __attribute__((ext_vector_type(3), aligned(1)));
+
+// lane i takes x of lane i - 1; lane 0 takes `first`
+__device__ __forceinline__ int wave_shr1i(int x, int first) { return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xf, 0xf, false); }
+
+// Integer sample of derived row ROW (0 L, 1 R, 2 L + R = twice the mid row, 3 side = L - R;
+// main.c:198-207) from NW dwords that hold the instant's two channels from byte O on.
+template <int ROW, int O, int NW>
+__device__ __forceinline__ int row_int(const unsigned (&d)[NW])
+{
+    if constexpr (ROW == 0) return window_sample<3, O, NW>(d);
+    else if constexpr (ROW == 1) return window_sample<3, O + 3, NW>(d);
+    else if constexpr (ROW == 2) return window_sample<3, O, NW>(d) + window_sample<3, O + 3, NW>(d);
+    else return window_sample<3, O, NW>(d) - window_sample<3, O + 3, NW>(d);
+}
+
+// own[r] = the 12 bytes of instants 2n and 2n+1, n = l + 64 r -> xa[r], xb[r]; pred = the 8 bytes in
+// front of the frame's first instant (its predecessor: bytes 2 .. 7) -> pred0
+template <int NZ, int ROW>
+__device__ __forceinline__ void pipew_samples(int (&xa)[NZ], int (&xb)[NZ], int &pred0, const unsigned (&own)[NZ][3], const unsigned (&pred)[2])
+{
+#pragma unroll
+    for (int r = 0; r < NZ; ++r) {
+        xa[r] = row_int<ROW, 0, 3>(own[r]);
+        xb[r] = row_int<ROW, 6, 3>(own[r]);
+    }
+    pred0 = row_int<ROW, 2, 2>(pred);
+}
+
+// The lane's points (2n, 2n+1), n = l + 64 r, of the frame's row from its integer samples xa[r] =
+// x[2n], xb[r] = x[2n+1] (pred0: the sample in front of the frame; row 2 holds L + R, and `scale`
+// = 0.5 then goes into the window values: scaling by a power of two commutes with every rounding
+// here).  The predecessor 2n-1 of a pair is the second sample of the previous lane's pair (of lane
+// 63's previous pair for lane 0): one lane shift.  Pre-emphasis over the whole signal in double
+// with separately rounded product and difference (PreEmphasise main.c:208; first-sample rule for
+// the signal's first sample), Hamming window (main.c:229, pairs from winL); with ZC the zero
+// crossings of the un-windowed samples (main.c:227), counted over the wave with mask popcounts
+// (sample 2n+2 is the next lane's first sample).
+template <int NZ, bool ZC>
+__device__ __forceinline__ void pipew_expand(cpx<double> (&v)[16], int &zc, const int (&xa)[NZ], const int (&xb)[NZ], int pred0, double scale,
+                                             int l, const cpx<double> *winL, double preK, bool firstTile, int wlen)
+{
+    constexpr int G = 64;
+    double nextFirst0 = 0; // sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r)
+#pragma unroll
+    for (int r = NZ - 1; r >= 0; --r) {
+        int carry = pred0;
+        if (r > 0) carry = __builtin_amdgcn_readlane(xb[r - 1], 63);
+        const double x0 = (double)wave_shr1i(xb[r], carry), x1 = (double)xa[r], x2 = (double)xb[r];
+        double y1 = sub_mul_exact(x1, x0, preK);
+        const double y2 = sub_mul_exact(x2, x1, preK);
+        if (firstTile && l == 0 && r == 0) y1 = x1 * (1.0 - preK); // s[1] *= 1 - k
+        if constexpr (ZC) {
+            const double x3 = wave_shl1d(y1, nextFirst0);
+            // (opposite signs = negative product; the samples are far from the underflow range)
+            bool c01 = y1 * y2 < 0.0, c12 = y2 * x3 < 0.0;
+            // pairs inside the frame only (an instance serves every window length up to 128 NZ)
+            const int s0 = 2 * (l + G * r);
+            c01 = c01 && s0 + 1 < wlen;
+            c12 = c12 && s0 + 2 < wlen;
+            zc += __builtin_popcountll(__builtin_amdgcn_ballot_w64(c01)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c12));
+            const long long yb = __double_as_longlong(y1);
+            nextFirst0 = __longlong_as_double(((long long)sgpr((int)(yb >> 32)) << 32) | (unsigned)sgpr((int)yb));
+        }
+        const cpx<double> w = winL[l + G * r];
+        v[r] = cpx<double>{y1 * (w.x * scale), y2 * (w.y * scale)};
+    }
+#pragma unroll
+    for (int r = NZ; r < 16; ++r) v[r] = cpx<double>{0.0, 0.0};
+}
+
+} // namespace
+
+// NZ: first-stage inputs of a lane that can be non-zero (14 for frames of at most 1792 samples,
+// else 16).  ZCT: zero-crossing rate on.
+template <int NZ, bool ZCT>
+__global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs<double> a)
+{
+    constexpr int NC = 1024, G = 64, PPL = 16, NPAIR = 8, WAVES = kPipeWideWaves;
+    constexpr int NPL = 2;          // mel parts per lane
+    constexpr int ZP = NC + NC / 16; // doubles per work area
+    constexpr int kClampFrom = 8;   // pairs from here on can lie behind the shortest frame's last byte
+    typedef double T;
+    STAMP_DECL
+    STAMP_START;
+    const int tid = threadIdx.x;
+    const int wave = sgpr(tid >> 6);
+    const int tt0 = tid & 63;
+    int tt = tt0, l = tt0;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *lwL = reinterpret_cast<T *>(smem);
+    cpx<T> *winL = reinterpret_cast<cpx<T> *>(lwL + NC + 8);
+    int4 *segL = reinterpret_cast<int4 *>(winL + NZ * G);
+    T *dctL = reinterpret_cast<T *>(segL + kPipeParts + 64);
+    const bool dctInLds = a.rowPitch > 0; // (rowPitch: elements of the table's copy)
+    T *Zt = reinterpret_cast<T *>(smem) + a.tabElems + (size_t)wave * a.teamElems;
+    cpx<T> *Zc = reinterpret_cast<cpx<T> *>(Zt);
+    T *Pw = Zt;
+
+    for (int i = tid; i < NC + 8; i += WAVES * 64) lwL[i] = i < NC ? a.loWt[i] : (T)0;
+    for (int i = tid; i < NZ * G; i += WAVES * 64) winL[i] = reinterpret_cast<const cpx<T> *>(a.window)[i];
+    for (int i = tid; i < kPipeParts + 64; i += WAVES * 64) segL[i] = reinterpret_cast<const int4 *>(a.laneSeg)[i];
+    if (dctInLds) {
+        for (int i = tid; i < a.dctElems; i += WAVES * 64) dctL[i] = a.dctT[i];
+    }
+    // every value a masked sum may read from a work area is a finite number from here on
+    for (int i = tt0; i < ZP; i += 64) Zt[i] = (T)0;
+    __syncthreads();
+    // Twiddle and split factors are read through L1 in the middle of a round: long after the
+    // previous round's result stores and before this round's.
+    const cpx<T> *twT = reinterpret_cast<const cpx<T> *>(a.tw), *swT = reinterpret_cast<const cpx<T> *>(a.splitTw);
+    const T *dctT = dctInLds ? dctL : a.dctT;
+    const T preK = a.preK;
+    const int JW = a.M + a.c0Flag;
+    const int F_V = a.V, F_S = a.S;
+    const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
+
+    // The wave's stream of tiles (chunks drawn from a.work, as in k_pipe64).
+    const int teamId = blockIdx.x * WAVES + wave, numTeams = gridDim.x * WAVES, C = a.tilesPerTeam;
+    int chunkBase = teamId * C, chunkPos = 0, nextBase = 0;
+    bool haveNext = false, needDraw = true;
+    auto draw = [&]() {
+        unsigned drawn = 0;
+        if (tt == 0) drawn = atomicAdd(a.work, 1u);
+        nextBase = (sgpr((int)drawn) + numTeams) * C;
+        haveNext = true;
+        needDraw = false;
+    };
+    auto next_tile = [&]() {
+        if (chunkPos == C) {
+            if (!haveNext) {
+                if (!needDraw) return -1;
+                draw();
+            }
+            chunkBase = nextBase;
+            chunkPos = 0;
+            haveNext = false;
+            needDraw = chunkBase < a.numTiles;
+        }
+        const int id = chunkBase + chunkPos;
+        if (id >= a.numTiles) return -1;
+        ++chunkPos;
+        return id;
+    };
+    auto draw_step = [&]() {
+        if (needDraw && !haveNext) draw();
+    };
+    auto next_tile_s = [&]() {
+        const int id = sgpr(next_tile());
+        chunkBase = sgpr(chunkBase);
+        chunkPos = sgpr(chunkPos);
+        nextBase = sgpr(nextBase);
+        return id;
+    };
+    auto finish = [&]() {
+        __threadfence();
+        if (tt == 0 && atomicInc(a.work + 1, (unsigned)numTeams - 1u) == (unsigned)numTeams - 1u) {
+            __hip_atomic_store(a.work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (chunkBase >= a.numTiles) {
+        finish();
+        STAMP_FLUSH;
+        return;
+    }
+    const TileDesc *tab = a.tiles;
+    int id = next_tile_s();
+    PipeTile cur = pipe_desc(tab, id, true);
+    id = next_tile_s();
+    PipeTile nx = pipe_desc(tab, id < 0 ? 0 : id, id >= 0);
+    id = next_tile_s();
+    PipeTile nn = pipe_desc(tab, id < 0 ? 0 : id, id >= 0);
+
+    // The frame's raw bytes as the lanes need them: one path for every frame, so that the loaded
+    // registers have a single definition and nothing waits for them where they are asked for.  A
+    // frame at the last bytes of the buffer (edge) moves the loads that would pass the end back
+    // to it, one at its first bytes reads the predecessor from the buffer's start; fix_raw then
+    // shifts those bytes into place (zeros behind the end: they lie behind the frame's last sample).
+    auto load_raw = [&](const PipeTile &t, unsigned (&own)[NZ][3], unsigned (&pred)[2]) {
+        const long long src = t.src();
+        const unsigned char *g = a.pcm + src;
+        const int lastAt = t.edge() ? (int)min(a.planEnd - src, (long long)(1 << 30)) - 12 : 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < NZ; ++r) {
+            u3u q;
+            // (a uniform pointer per pair plus one unsigned lane offset: scalar address arithmetic)
+            if (r < kClampFrom) q = *reinterpret_cast<const u3u *>(g + 12 * G * r + 12u * (unsigned)tt);
+            else q = *reinterpret_cast<const u3u *>(g + min(12 * (tt + G * r), lastAt));
+            own[r][0] = q.x, own[r][1] = q.y, own[r][2] = q.z;
+        }
+        const u2u pq = *reinterpret_cast<const u2u *>(g - (src >= 8 ? 8 : src));
+        pred[0] = pq.x, pred[1] = pq.y;
+    };
+    auto fix_raw = [&](const PipeTile &t, unsigned (&own)[NZ][3], unsigned (&pred)[2]) {
+        if (t.edge()) {
+            const long long src = t.src();
+            const int lastAt = (int)min(a.planEnd - src, (long long)(1 << 30)) - 12;
+#pragma unroll
+            for (int r = kClampFrom; r < NZ; ++r) {
+                const int back = max(12 * (tt + G * r) - lastAt, 0); // bytes the load was moved back by
+                const int words = back >> 2;
+                const unsigned q0 = own[r][0], q1 = own[r][1], q2 = own[r][2];
+                const unsigned e0 = words == 0 ? q0 : words == 1 ? q1 : words == 2 ? q2 : 0u;
+                const unsigned e1 = words == 0 ? q1 : words == 1 ? q2 : 0u;
+                const unsigned e2 = words == 0 ? q2 : 0u;
+                own[r][0] = __builtin_amdgcn_alignbyte(e1, e0, (unsigned)back & 3u);
+                own[r][1] = __builtin_amdgcn_alignbyte(e2, e1, (unsigned)back & 3u);
+                own[r][2] = __builtin_amdgcn_alignbyte(0u, e2, (unsigned)back & 3u);
+            }
+            if (src < 8) { // the 8 bytes were read from the buffer's start: its first `src` are the wanted last ones
+                const unsigned long long both = ((unsigned long long)pred[1] << 32) | pred[0];
+                const unsigned long long moved = src > 0 ? both << (8 * (8 - (int)src)) : 0ull;
+                pred[0] = (unsigned)moved, pred[1] = (unsigned)(moved >> 32);
+            }
+        }
+    };
+
+    // The integer samples of the round to come, carried from round to round.
+    int xa[NZ], xb[NZ], pred0;
+    auto to_samples = [&](const int row, const unsigned (&own)[NZ][3], const unsigned (&pred)[2]) {
+        switch (row) { // (the same for every lane)
+        case 0: pipew_samples<NZ, 0>(xa, xb, pred0, own, pred); break;
+        case 1: pipew_samples<NZ, 1>(xa, xb, pred0, own, pred); break;
+        case 2: pipew_samples<NZ, 2>(xa, xb, pred0, own, pred); break;
+        default: pipew_samples<NZ, 3>(xa, xb, pred0, own, pred); break;
+        }
+    };
+    {
+        unsigned own[NZ][3], pred[2];
+        load_raw(cur, own, pred);
+        fix_raw(cur, own, pred);
+        to_samples(0, own, pred);
+    }
+
+    T lvr[4] = {0, 0, 0, 0}; // log-mel values of the lane's channel, per row
+
+    // One (frame, row) round.  LAST: the frame's last row, which also forms the cepstra.
+    auto round = [&](const int vv, auto lastTag) {
+        constexpr bool LAST = decltype(lastTag)::value;
+        // (the lane index is made opaque once per round: what derives from it is recomputed here in
+        // a few instructions instead of being kept in registers, or spilled, across the whole loop)
+        asm volatile("" : "+v"(tt));
+        l = tt & 63;
+        const bool firstTile = cur.first();
+        T *fo = a.out + (long long)cur.outRow * a.step + vv * a.D;
+        STAMP(0);
+
+        // ---- the lane's points of derived row vv from its samples (rows main.c:198-207), pre-emphasis
+        //      (main.c:208), zero crossings (main.c:227), Hamming window (main.c:229), frame energy
+        //      (mfcc.c:138-142)
+        cpx<T> v[PPL];
+        int zcn = 0;
+        pipew_expand<NZ, ZCT>(v, zcn, xa, xb, pred0, vv == 2 ? 0.5 : 1.0, l, winL, preK, firstTile, a.wlen);
+        T te = 0;
+        if (a.energyFlag) {
+            cpx<T> e2 = {0, 0};
+#pragma unroll
+            for (int r = 0; r < NZ; ++r) e2 += v[r] * v[r];
+            te = frame_sum<G>((T)4 * (e2.x + e2.y)); // (the window table holds half the Hamming values)
+        }
+        STAMP(1);
+
+        // ---- 1024-point complex FFT of z[n] = x[2n] + i x[2n+1] (Realft mfcc.c:262-270): Stockham
+        //      stages of radix 16, 16 and 4, real parts and imaginary parts exchanged in turn
+        Radix<T, 16>::run(v);
+        {
+            T *wp = Zt + 17 * l;                                 // zpad(16 l + r) = 17 l + r
+            const T *rp = Zt + l + (l >> 4);                     // zpad(l + G r) = zpad(l) + (G + G / 16) r
+            constexpr int RS = G + G / 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[r] = v[r].x;
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r].x = rp[RS * r];
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[r] = v[r].y;
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r].y = rp[RS * r];
+            wave_fence();
+        }
+        const unsigned lu = (unsigned)tt; // (one unsigned lane offset under uniform row pointers: scalar address arithmetic)
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], (twT + (r - 1) * 16)[lu & 15u]); // sub-transform size 16: [r-1][l mod 16]
+        Radix<T, 16>::run(v);
+        {
+            const int o = ((l >> 4) << 8) + (l & 15);
+            T *wp = Zt + o + (o >> 4);                           // zpad(o + 16 r) = zpad(o) + 17 r
+            const T *rp = Zt + l + (l >> 4);                     // zpad(l + 64 b + 256 r) = zpad(l) + 68 b + 272 r
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[17 * r] = v[r].x;
+            wave_fence();
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * b + r].x = rp[68 * b + 272 * r];
+            wave_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[17 * r] = v[r].y;
+            wave_fence();
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * b + r].y = rp[68 * b + 272 * r];
+            wave_fence();
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 1; r < 4; ++r) v[4 * b + r] = cmul(v[4 * b + r], (twT + (15 * 16 + (r - 1) * 256 + 64 * b))[lu]); // size 256: [r-1][l + 64 b]
+#pragma unroll
+            for (int b = 0; b < 4; ++b) Radix<T, 4>::run(&v[4 * b]);
+        }
+        // the lane now holds X[l + G m], m = 0 .. 15, in register xr(m)
+        auto xr = [&](int m) -> cpx<T> & { return v[4 * (m & 3) + (m >> 2)]; };
+        STAMP(3);
+
+        // ---- real-FFT split and power (mfcc.c:274-290, ek of mfcc.c:153-155): the upper half of the
+        //      spectrum goes through the work area (complex index = bin - NC / 2) and the lane reads
+        //      back X[NC - l - G q], q = 0 .. 7 (lane 0, q = 0: one point past the bins, unused)
+        T pa[NPAIR], pb[NPAIR];
+        {
+#pragma unroll
+            for (int m = 8; m < 16; ++m) Zc[l + G * (m - 8)] = xr(m);
+            wave_fence();
+            cpx<T> rev[NPAIR];
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) rev[q] = Zc[NC / 2 - l - G * q];
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) split_power<T>(xr(q), rev[q], (swT + G * q)[lu], pa[q], pb[q]);
+            // bin 0 packs Re + Im of X[0] (mfcc.c:288-290); bin NC / 2 is |X[NC / 2]|^2; lane 0 holds both
+            const cpx<T> z0 = xr(0), zh = xr(8);
+            const T p0 = (T)4 * (z0.x + z0.y) * (z0.x + z0.y);
+            const T ph = (T)4 * (zh.x * zh.x + zh.y * zh.y);
+            pa[0] = l == 0 ? p0 : pa[0];
+            pb[0] = l == 0 ? ph : pb[0];
+        }
+        wave_fence(); // every lane has read its partner points: the area takes the power values, bin order
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            const int k = l + G * q;
+            const int k2 = k == 0 ? NC / 2 : NC - k;
+            Pw[k] = pa[q];
+            Pw[k2] = pb[q];
+        }
+        wave_fence();
+        STAMP(4);
+
+        // ---- the bytes of the round to come (this frame's next row, or the next frame's first)
+        unsigned own[NZ][3], pred[2];
+        if constexpr (LAST) {
+            if (nx.valid()) draw_step();
+            load_raw(nx.valid() ? nx : cur, own, pred); // (behind the last frame: this one's again, unused)
+        } else {
+            load_raw(cur, own, pred);
+        }
+
+        // ---- sub-band energies / brightness (main.c:235-236): every band (the whole spectrum when
+        //      only the brightness is asked for) gets a power-of-two share of the frame's lanes
+        T bandOut = 0, brightOut = 0; // (stored with the round's other results, at its end)
+        int bandAt = -1;
+        if (F_S > 0 || a.brightFlag) {
+            const int nseg = F_S > 0 ? F_S : 1, width = NC / nseg; // (nseg <= G: one pass)
+            int lpb = 1;
+            while (lpb * 2 * nseg <= G) lpb *= 2;
+            const int b = l / lpb, sl = l & (lpb - 1);
+            T e = 0, ek = 0;
+            if ((nseg & (nseg - 1)) == 0) {
+                // Bands of a power-of-two width lie a multiple of the banks' span apart: the lanes of
+                // band b start lpb b bins into it and wrap around, so that the bands' simultaneous
+                // reads fall into different banks (the sums only change their order).
+                const int lo = b * width, rot = sl + lpb * b; // (16 steps of lpb bins)
+#pragma unroll
+                for (int i0 = 0; i0 < 16; i0 += 8) {
+                    T pv[8];
+                    int kk[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        kk[i] = lo + ((rot + (i0 + i) * lpb) & (width - 1));
+                        pv[i] = Pw[kk[i]];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        e += pv[i];
+                        ek += (T)(kk[i] + 1) * pv[i];
+                    }
+                }
+            } else if (b < nseg) {
+                const int lo = b * width, hi = (b == nseg - 1) ? NC : lo + width;
+                for (int k = lo + sl; k < hi; k += 4 * lpb) { // four reads in flight
+                    T pv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pv[i] = Pw[min(k + i * lpb, NC - 1)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool in = k + i * lpb < hi;
+                        e += in ? pv[i] : (T)0;
+                        ek += in ? (T)(k + i * lpb + 1) * pv[i] : (T)0;
+                    }
+                }
+            }
+            for (int o = lpb >> 1; o > 0; o >>= 1) {
+                e += __shfl_xor(e, o, 64);
+                ek += __shfl_xor(ek, o, 64);
+            }
+            // the band's sums sit in its first lane; totals over the frame's bands
+            const bool head = b < nseg && sl == 0;
+            const T total = frame_sum<G>(head ? e : (T)0), num = frame_sum<G>(head ? ek : (T)0);
+            if (F_S > 0 && head) bandOut = e / total, bandAt = subAt + b;
+            brightOut = num / total / (T)NC;
+        }
+        const T teOut = a.energyFlag ? fast_log(te) : (T)0;
+        STAMP(5);
+
+        // ---- mel filterbank (mfcc.c:152-163): the bins whose lower channel is c form one segment,
+        //      cut by the host into parts; a lane sums Tc = sum loWt p and Uc = sum (p - loWt p) of its
+        //      parts in bin order, the part sums go to the work area, and the lane of channel b adds the
+        //      parts of U[b-1] and of T[b] in part (= bin) order; then log(max(., 1)) (mfcc.c:171-176)
+        T ps[NPL][2];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int4 sg = segL[l + G * j];
+            const int pB = sg.x, pE = sg.z >= 0 ? sg.y : sg.x;
+            T accT = 0, accU = 0;
+            for (int k = pB; k < pE; k += 4) {
+                T pv[4], wv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pv[i] = Zt[k + i]; // (reads past the part stay inside the area / the weight table's zero tail)
+                    wv[i] = lwL[k + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool in = k + i < pE;
+                    const T t1 = wv[i] * pv[i];
+                    accT += in ? t1 : (T)0;
+                    accU += in ? pv[i] - t1 : (T)0;
+                }
+            }
+            ps[j][0] = accT;
+            ps[j][1] = accU;
+        }
+        wave_fence(); // every part has been read: the bins' place takes the part sums
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            Zt[l + G * j] = ps[j][0];
+            Zt[kPipeParts + l + G * j] = ps[j][1];
+        }
+        wave_fence();
+        T lv = 0;
+        {
+            const int4 cp = l < a.P ? segL[kPipeParts + l] : make_int4(0, 0, 0, 0);
+            T pu[10], pt[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                pu[i] = Zt[kPipeParts + cp.x + i];
+                pt[i] = Zt[cp.z + i];
+            }
+            T mu = 0, mt = 0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                mu += i < cp.y ? pu[i] : (T)0;
+                mt += i < cp.w ? pt[i] : (T)0;
+            }
+            const T m = mu + mt;
+            lv = fast_log(m < (T)1 ? (T)1 : m);
+            if (l < a.P && !a.fbankFlag) {
+                lvr[0] = vv == 0 ? lv : lvr[0];
+                lvr[1] = vv == 1 ? lv : lvr[1];
+                lvr[2] = vv == 2 ? lv : lvr[2];
+                lvr[3] = vv == 3 ? lv : lvr[3];
+            }
+        }
+        wave_fence(); // the work area is free again
+        STAMP(6);
+
+        // ---- the next round's samples, then this round's results (row layout main.c:241-249)
+        fix_raw(LAST && nx.valid() ? nx : cur, own, pred);
+        to_samples(LAST ? 0 : vv + 1, own, pred);
+        if (bandAt >= 0) fo[bandAt] = bandOut;
+        if (l == 0) {
+            if (a.brightFlag) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = brightOut;
+            if (a.energyFlag) fo[a.M + a.c0Flag] = teOut;                                      // main.c:243
+            if (a.zcFlag) fo[a.M + a.c0Flag + a.energyFlag] = (T)zcn / (T)(a.wlen - 1);        // main.c:244
+        }
+        if (a.fbankFlag && l < a.P) fo[l] = lv;
+        if constexpr (LAST) {
+            if (!a.fbankFlag) {
+                // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208): the frame's
+                //      log-mel values go to the work area as [channel][row]; lane j forms coefficient
+                //      j of every row from its table row (row M is all ones: C0)
+                auto cepstra = [&](auto rowsTag) {
+                    constexpr int VV = decltype(rowsTag)::value;
+                    if (l < a.P) {
+#pragma unroll
+                        for (int vq = 0; vq < VV; ++vq) Zt[l * VV + vq] = lvr[vq];
+                    }
+                    wave_fence();
+                    T *orow = a.out + (long long)cur.outRow * a.step;
+                    for (int j0 = 0; j0 < JW; j0 += G) {
+                        const int j = j0 + l;
+                        const T *row = dctT + (j < JW ? j : JW - 1) * a.dctPitch;
+                        T acc[VV];
+#pragma unroll
+                        for (int vq = 0; vq < VV; ++vq) acc[vq] = 0;
+                        for (int k0 = 0; k0 < a.P; k0 += 4) {
+                            T tv[4], f[4][VV];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int k = min(k0 + u, a.P - 1);
+                                tv[u] = k0 + u < a.P ? row[k] : (T)0;
+#pragma unroll
+                                for (int vq = 0; vq < VV; ++vq) f[u][vq] = Zt[k * VV + vq];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int vq = 0; vq < VV; ++vq) acc[vq] += tv[u] * f[u][vq];
+                        }
+                        if (j < JW) {
+#pragma unroll
+                            for (int vq = 0; vq < VV; ++vq) orow[vq * a.D + j] = acc[vq] * a.mfnorm;
+                        }
+                    }
+                };
+                switch (F_V) {
+                case 1: cepstra(std::integral_constant<int, 1>{}); break;
+                case 2: cepstra(std::integral_constant<int, 2>{}); break;
+                case 3: cepstra(std::integral_constant<int, 3>{}); break;
+                default: cepstra(std::integral_constant<int, 4>{}); break;
+                }
+                wave_fence(); // the work area is free for the next frame
+            }
+        }
+        STAMP(9);
+    };
+    for (;;) {
+        // the descriptor three tiles ahead: asked for now, moved into place at the tile's end
+        const int id3 = next_tile_s();
+        const PipeTile d3 = pipe_desc(tab, id3 < 0 ? 0 : id3, id3 >= 0);
+        for (int vv = 0; vv + 1 < F_V; ++vv) round(vv, std::false_type{});
+        round(F_V - 1, std::true_type{});
+        if (!nx.valid()) break;
+        cur = nx;
+        nx = nn;
+        nn = d3;
+    }
+    finish();
+    STAMP_FLUSH;
+}
+
+// ------------------------------------------------------------------------------------------
 // Geometry the host plans with.
 // ------------------------------------------------------------------------------------------
 
@@ -830,13 +1396,10 @@ int pipe64_class(int log2nc, int channels, int bps, int wlen, int inc)
         const long bytes = ((long)3 * inc + wlen + 1) * 2;
         return bytes <= 2 * 64 * 16 ? 8 : 0;
     }
-    if (log2nc == 10 && channels == 2 && bps == 3 && wlen > 1024) {
-        const long bytes = ((long)wlen + 1) * 6;
-        return bytes <= 11 * 64 * 16 ? 10 : 0;
-    }
+    if (log2nc == 10 && channels == 2 && bps == 3 && wlen > 1024 && wlen <= 2048) return 10;
     return 0;
 }
-int pipe64_waves() { return kPipeWaves; }
+int pipe64_waves(int cls) { return cls == 8 ? kPipeWaves : kPipeWideWaves; }
 int pipe64_frames_per_tile(int cls) { return cls == 8 ? 4 : 1; }
 int pipe64_lanes(int cls) { return cls == 8 ? 16 : 64; }
 int pipe64_nz(int cls, int wlen)
@@ -845,24 +1408,30 @@ int pipe64_nz(int cls, int wlen)
     const int nz = (wlen + per - 1) / per;
     return cls == 8 ? (nz <= 13 ? 13 : 16) : (nz <= 14 ? 14 : 16);
 }
-// LDS bytes of one wave's raw PCM area: the tile's bytes.  (A lane also reads the instants behind
-// the frame's last sample up to the end of its first-stage inputs, where the window is zero: those
-// reads may run into the wave's own work area, which follows the raw bytes and is larger.)
+// LDS bytes of one wave's raw PCM area: the tile's bytes (256-point class; the 1024-point class
+// reads its bytes straight from memory).  (A lane also reads the instants behind the frame's last
+// sample up to the end of its first-stage inputs, where the window is zero: those reads may run
+// into the wave's own work area, which follows the raw bytes and is larger.)
 int pipe64_raw_bytes(int cls, int wlen, int inc)
 {
+    if (cls != 8) return 0;
     const int gt = pipe64_frames_per_tile(cls), bpi = cls == 8 ? 2 : 6;
     const long tile = ((long)(gt - 1) * inc + wlen + 1) * bpi;
     return (int)((tile + 15 + 16) & ~15L);
 }
 int pipe64_area_elems(int cls) { return (1 << cls) + (1 << cls) / 16; }
-// shared tables in front of the waves' regions, in doubles
+// shared tables in front of the waves' regions, in doubles (1024-point class: filterbank weights,
+// window pairs, the lanes' mel part tables; its cepstral table follows them when the plan finds room)
 int pipe64_tab_elems(int cls, int wlen, int dctElems, int melSteps)
 {
     const int nc = 1 << cls;
     int n = cls == 8 ? melSteps * 64 : nc + 8;
     if (cls == 8) n += 2 * (pipe64_nz(cls, wlen) * 16 + 15 * 16 + nc / 2) + dctElems;
+    else n += 2 * pipe64_nz(cls, wlen) * 64 + (kPipeParts + 64) * 2;
     return (n + 1) & ~1;
 }
+// bytes from a frame's first instant that the 1024-point class's loads reach (12 per sample pair)
+int pipe64_reach_bytes(int wlen) { return 12 * 64 * pipe64_nz(10, wlen); }
 
 template <int LOG2NC, int CH, int BPS, int NZ, bool ZCT>
 static int launch_pipe_t(const FrontArgs<double> &a, int numBlocks, size_t lds, hipStream_t st)
@@ -874,13 +1443,23 @@ static int launch_pipe_t(const FrontArgs<double> &a, int numBlocks, size_t lds, 
     return (int)hipGetLastError();
 }
 
+template <int NZ, bool ZCT>
+static int launch_pipew_t(const FrontArgs<double> &a, int numBlocks, size_t lds, hipStream_t st)
+{
+    static std::atomic<bool> attrSet[kAttrDevices];
+    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_pipe64w<NZ, ZCT>), attrSet);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_pipe64w<NZ, ZCT>), dim3(numBlocks), dim3(kPipeWideWaves * 64), lds, st, a);
+    return (int)hipGetLastError();
+}
+
 int launch_pipe64(const FrontArgs<double> &a, int cls, int numBlocks, size_t lds, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nz = pipe64_nz(cls, a.wlen);
     if (cls == 8) return nz == 13 ? launch_pipe_t<8, 1, 2, 13, false>(a, numBlocks, lds, st) : launch_pipe_t<8, 1, 2, 16, false>(a, numBlocks, lds, st);
-    if (a.zcFlag) return nz == 14 ? launch_pipe_t<10, 2, 3, 14, true>(a, numBlocks, lds, st) : launch_pipe_t<10, 2, 3, 16, true>(a, numBlocks, lds, st);
-    return nz == 14 ? launch_pipe_t<10, 2, 3, 14, false>(a, numBlocks, lds, st) : launch_pipe_t<10, 2, 3, 16, false>(a, numBlocks, lds, st);
+    if (a.zcFlag) return nz == 14 ? launch_pipew_t<14, true>(a, numBlocks, lds, st) : launch_pipew_t<16, true>(a, numBlocks, lds, st);
+    return nz == 14 ? launch_pipew_t<14, false>(a, numBlocks, lds, st) : launch_pipew_t<16, false>(a, numBlocks, lds, st);
 }
 
 } // namespace mfcc
