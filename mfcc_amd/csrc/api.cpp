@@ -834,7 +834,9 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
         p->melSteps = 0;
         if (!(pipeCls == 8 ? pipe64_mel_matrix(p, tune.debug != 0) : pipe64_part_table(p, pipeCls, tune.debug != 0))) return choose_tile(p, false);
         int tabL = pipe64_tab_elems(pipeCls, c->cfg.wlen, c->dctElems, p->melSteps);
-        size_t bytes = ((size_t)tabL + (size_t)pipe64_waves(pipeCls) * teamL) * sizeof(double);
+        const bool fits12 = ((size_t)tabL + (size_t)12 * teamL) * sizeof(double) <= kLds;
+        const int pipeWaves = pipe64_waves(pipeCls, fits12);
+        size_t bytes = ((size_t)tabL + (size_t)pipeWaves * teamL) * sizeof(double);
         if (bytes > kLds) return choose_tile(p, false);
         int dctLdsEl = 0; // 1024-point class: the cepstral table shares the LDS when there is room
         if (pipeCls == 10 && c->dctElems > 0 && bytes + (((size_t)c->dctElems + 1) & ~(size_t)1) * sizeof(double) <= kLds) {
@@ -850,13 +852,13 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
         p->featElems = 0;
         p->teamElems = teamL;
         p->tabElems = tabL;
-        p->activeTeams = pipe64_waves(pipeCls);
+        p->activeTeams = pipeWaves;
         p->ldsBytes = bytes;
         p->blocksPerCu = 1;
         p->mode = 0;
         if (tune.debug)
             fprintf(stderr, "mfcc plan: double-precision pipelined kernel, %d complex points, %d waves per workgroup, LDS %zu B\n", 1 << pipeCls,
-                    pipe64_waves(pipeCls), bytes);
+                    pipeWaves, bytes);
         return MFCC_OK;
     }
     if (wideCand) {
@@ -1552,7 +1554,7 @@ static int run_front(MFCCContext *c, MFCCPlan *p, const void *pcmDev, void *outD
             a.planEnd = p->planEnd;
             a.tilesPerTeam = chunk;
             a.work = p->dWork;
-            const int rcp = launch_pipe64(a, p->pipe64, nb, p->ldsBytes, stream);
+            const int rcp = launch_pipe64(a, p->pipe64, waves, nb, p->ldsBytes, stream);
             if (rcp) return set_error("static-feature kernel launch failed (HIP error %d)", rcp), MFCC_E_DEVICE;
             return MFCC_OK;
         }

@@ -196,14 +196,14 @@ int wide1024_reach_bytes(int wlen);       // bytes from a frame's first instant 
 int launch_wide1024(const FrontArgs<float> &a, int numBlocks, size_t ldsBytes, void *stream);
 // pipe64.hip: double precision, mono 16-bit with 256 complex points or 24-bit stereo with 1024
 int pipe64_class(int log2nc, int channels, int bps, int wlen, int inc); // 0: not taken, else 8 or 10
-int pipe64_waves(int cls);
+int pipe64_waves(int cls, bool fits12);   // waves per workgroup (256-point class: 12 when that many regions fit the LDS, else 8)
 int pipe64_frames_per_tile(int cls);
 int pipe64_lanes(int cls);                // lanes that share one frame
 int pipe64_raw_bytes(int cls, int wlen, int inc); // LDS bytes a wave reserves for a tile's raw PCM
 int pipe64_area_elems(int cls);           // doubles per frame work area
 int pipe64_tab_elems(int cls, int wlen, int dctElems, int melSteps); // doubles of the shared tables in LDS
 int pipe64_reach_bytes(int wlen);          // 1024-point class: bytes from a frame's first instant that its loads reach
-int launch_pipe64(const FrontArgs<double> &a, int cls, int numBlocks, size_t ldsBytes, void *stream);
+int launch_pipe64(const FrontArgs<double> &a, int cls, int waves, int numBlocks, size_t ldsBytes, void *stream);
 bool front_variant_exists(int log2nc, int pplog); // pplog: log2 of complex points per lane (4, 3, 2)
 int front_groups(int log2nc, int pplog);          // frames in flight per workgroup
 int front_teams(int log2nc, int pplog);           // independent teams (tile streams) per workgroup

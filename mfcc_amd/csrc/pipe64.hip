@@ -1,23 +1,23 @@
-// Double-precision static-feature kernel for the two input classes the benchmarks name: mono 16-bit
-// PCM with frames of at most 512 samples (256 complex points, 16 lanes x 16 points per frame, four
-// frames per wave) and 24-bit stereo PCM with frames of 1025 .. 2048 samples (1024 complex points,
-// 64 lanes x 16 points, one frame per wave).  The reference computes in double throughout
-// (rows main.c:198-207, PreEmphasise main.c:208, zeroCrossingRate main.c:227, Ham main.c:229,
-// Wave2FBank mfcc.c:125-177, brightness / sub-bands main.c:235-236, FBank2MFCC / FBank2C0
-// mfcc.c:180-208, row layout main.c:241-249); this kernel is its arithmetic at that precision,
-// organised as the single-precision kernels of lean256.hip / wide1024.hip are:
-//   - a wave is a team of its own (wave-level synchronisation only), eight waves per workgroup, one
-//     workgroup per CU; waves draw chunks of consecutive tiles from a shared counter;
-//   - a tile is one round of frames (4 or 1).  What a wave keeps of it in LDS is the RAW interleaved
-//     PCM bytes; every (frame, row) round expands the instants a lane needs straight from them, in
-//     double with separately rounded product and difference, so every sample (and its sign, for
-//     the zero crossings) is the reference's bit for bit;
+// Double-precision static-feature kernels for the two input classes the benchmarks name: mono 16-bit
+// PCM with frames of at most 512 samples (k_pipe64: 256 complex points, 16 lanes x 16 points per
+// frame, four frames per wave) and 24-bit stereo PCM with frames of 1025 .. 2048 samples (k_pipe64w:
+// 1024 complex points, 64 lanes x 16 points, one frame per wave).  The reference computes in double
+// throughout (rows main.c:198-207, PreEmphasise main.c:208, zeroCrossingRate main.c:227, Ham
+// main.c:229, Wave2FBank mfcc.c:125-177, brightness / sub-bands main.c:235-236, FBank2MFCC /
+// FBank2C0 mfcc.c:180-208, row layout main.c:241-249); these kernels are its arithmetic at that
+// precision, organised as the single-precision kernels of lean256.hip / wide1024.hip are:
+//   - a wave is a team of its own (wave-level synchronisation only), twelve waves per workgroup
+//     (eight when twelve regions of the 256-point class do not fit the LDS), one workgroup per CU;
+//     waves draw chunks of consecutive tiles from a shared counter;
+//   - a tile is one round of frames (4 or 1).  Every (frame, row) round forms its samples from the
+//     RAW interleaved PCM bytes -- kept in LDS per tile (256-point class) or read straight from
+//     memory a round ahead (1024-point class) -- in double with separately rounded product and
+//     difference, so every sample (and its sign, for the zero crossings) is the reference's bit
+//     for bit;
 //   - a work area holds one double per complex point: the transposing exchanges between the FFT
 //     stages move real and imaginary parts one after the other (same LDS bandwidth, half the
 //     footprint), the last stage stays in registers, and only the upper half of the spectrum
-//     goes through the area again for the real-FFT split;
-//   - the next tile's bytes are requested into registers during the round and stored over the
-//     current ones at its end.
+//     goes through the area again for the real-FFT split.
 #include <hip/hip_runtime.h>
 
 #include "front_util.h"
@@ -30,7 +30,7 @@ namespace mfcc {
 
 namespace {
 
-constexpr int kPipeWaves = 8;
+constexpr int kPipeWaves = 8; // (12 when the plan finds room in LDS, see pipe64_waves)
 constexpr int kPipeParts = 128; // entries of the mel part table (the channel table follows it)
 
 typedef unsigned int u4u __attribute__((ext_vector_type(4), aligned(1)));
@@ -122,88 +122,19 @@ __device__ __forceinline__ double wave_shl1d(double x, double last)
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-// 1024-point class: the lane's sample pairs (2n, 2n+1), n = l + 64 r, of derived row ROW (0 L, 1 R,
-// 2 mid = 0.5 (L+R), 3 side = L - R; main.c:198-207) from the frame's raw 24-bit stereo bytes:
-// instants 2n-1 (the predecessor), 2n, 2n+1 of both channels are 18 bytes from byte 12 n on.
-// Pre-emphasis over the whole signal in double with separately rounded product and difference
-// (PreEmphasise main.c:208; first-sample rule for the signal's first sample), Hamming window
-// (main.c:229); with ZC the zero crossings of the un-windowed samples (main.c:227), counted over the
-// wave with mask popcounts (sample 2n+2 is the next lane's first sample).  Every read is issued
-// before the arithmetic; no branch inside.
-template <int NZ, bool ZC, int ROW>
-__device__ __forceinline__ void pipe_expand_wide(cpx<double> (&v)[16], int &zc, const unsigned *rawLane, int l, const cpx<double> *winLane,
-                                                 double preK, bool firstTile, int wlen)
-{
-    constexpr int G = 64;
-    unsigned own[NZ][5];
-    cpx<double> w[NZ];
-#pragma unroll
-    for (int r = 0; r < NZ; ++r) {
-        const unsigned *src = rawLane + 3 * G * r;
-        const u4u q = *reinterpret_cast<const u4u *>(src);
-        own[r][0] = q.x, own[r][1] = q.y, own[r][2] = q.z, own[r][3] = q.w;
-        own[r][4] = src[4];
-    }
-#pragma unroll
-    for (int r = 0; r < NZ; ++r) w[r] = winLane[G * r];
-    double nextFirst0 = 0; // sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r)
-#pragma unroll
-    for (int r = NZ - 1; r >= 0; --r) {
-        const unsigned(&d)[5] = own[r];
-        int c[3];
-        if constexpr (ROW == 0) {
-            c[0] = window_sample<3, 0, 5>(d), c[1] = window_sample<3, 6, 5>(d), c[2] = window_sample<3, 12, 5>(d);
-        } else if constexpr (ROW == 1) {
-            c[0] = window_sample<3, 3, 5>(d), c[1] = window_sample<3, 9, 5>(d), c[2] = window_sample<3, 15, 5>(d);
-        } else if constexpr (ROW == 2) { // L + R, halved below (the integer sum is exact)
-            c[0] = window_sample<3, 0, 5>(d) + window_sample<3, 3, 5>(d), c[1] = window_sample<3, 6, 5>(d) + window_sample<3, 9, 5>(d);
-            c[2] = window_sample<3, 12, 5>(d) + window_sample<3, 15, 5>(d);
-        } else {
-            c[0] = window_sample<3, 0, 5>(d) - window_sample<3, 3, 5>(d), c[1] = window_sample<3, 6, 5>(d) - window_sample<3, 9, 5>(d);
-            c[2] = window_sample<3, 12, 5>(d) - window_sample<3, 15, 5>(d);
-        }
-        double x[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) x[i] = ROW == 2 ? 0.5 * (double)c[i] : (double)c[i];
-        double y1 = sub_mul_exact(x[1], x[0], preK);
-        const double y2 = sub_mul_exact(x[2], x[1], preK);
-        if (firstTile && l == 0 && r == 0) y1 = x[1] * (1.0 - preK); // s[1] *= 1 - k
-        if constexpr (ZC) {
-            const double x2 = wave_shl1d(y1, nextFirst0);
-            // (opposite signs = negative product; the samples are far from the underflow range)
-            bool c01 = y1 * y2 < 0.0, c12 = y2 * x2 < 0.0;
-            // pairs inside the frame only (an instance serves every window length up to 128 NZ)
-            const int s0 = 2 * (l + G * r);
-            c01 = c01 && s0 + 1 < wlen;
-            c12 = c12 && s0 + 2 < wlen;
-            zc += __builtin_popcountll(__builtin_amdgcn_ballot_w64(c01)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c12));
-            const long long yb = __double_as_longlong(y1);
-            nextFirst0 = __longlong_as_double(((long long)sgpr((int)(yb >> 32)) << 32) | (unsigned)sgpr((int)yb));
-        }
-        v[r] = cpx<double>{y1 * w[r].x, y2 * w[r].y};
-    }
-#pragma unroll
-    for (int r = NZ; r < 16; ++r) v[r] = cpx<double>{0.0, 0.0};
-}
-
 } // namespace
 
-// LOG2NC: 8 (CH 1, BPS 2) or 10 (CH 2, BPS 3).  NZ: first-stage inputs of a lane that can be
-// non-zero, ceil(wlen / (2 G)).  ZCT (1024-point class): zero-crossing rate on.
-template <int LOG2NC, int CH, int BPS, int NZ, bool ZCT>
-__global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<double> a)
+// 256-point class (mono 16-bit, frames of at most 512 samples): four frames per wave.  NZ:
+// first-stage inputs of a lane that can be non-zero, ceil(wlen / 32).  WAVES: waves per workgroup.
+template <int NZ, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_pipe64(const FrontArgs<double> a)
 {
-    constexpr int NC = 1 << LOG2NC, G = NC / 16, GT = 64 / G, PPL = 16, NPAIR = 8, WAVES = kPipeWaves;
-    constexpr int BPI = CH * BPS;
-    constexpr int PFN = G == 16 ? 2 : 11;  // 16-byte vectors of a tile's fetch per lane
-    constexpr int NPL = G == 16 ? 4 : 2;   // mel parts per lane
-    constexpr int CHL = 64 / G;            // filterbank channels per lane
-    constexpr bool TABLDS = G == 16;       // window, twiddles, split factors and cepstral table in LDS
-    constexpr bool EARLY = PFN <= 2;       // the next tile's bytes are requested at the start of the round
+    constexpr int NC = 256, G = NC / 16, GT = 64 / G, PPL = 16, NPAIR = 8;
+    constexpr int BPI = 2;
+    constexpr int PFN = 2;                 // 16-byte vectors of a tile's fetch per lane
     constexpr int ZP = NC + NC / 16;       // doubles per work area
-    constexpr int DW = G == 16 ? 2 : 6;    // dwords a lane reads per sample pair: instants 2n-1 .. 2n+2
-    constexpr bool MELM = G == 16;         // mel filterbank of the wave's four frames on the matrix cores
-    constexpr int PP = 264;                // MELM: doubles between the four frames' power values (8 LDS banks apart)
+    constexpr int DW = 2;                  // dwords a lane reads per sample pair: instants 2n-1 .. 2n+2
+    constexpr int PP = 264;                // doubles between the four frames' power values (8 LDS banks apart)
     typedef double T;
     STAMP_DECL
     STAMP_START;
@@ -212,12 +143,11 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
     const int tt = tid & 63;
     const int l = tt & (G - 1), grp = tt / G;
 
-    // LDS: [filterbank weights (NC + 8, or the matrix-core table of melSteps x 64) | TABLDS: window
-    // pairs (NZ G) | twiddles (15 x 16) | split factors (NC / 2) | cepstral table] then one region
-    // per wave: [raw PCM bytes | GT work areas]
+    // LDS: [matrix-core filterbank table (melSteps x 64) | window pairs (NZ G) | twiddles (15 x 16) |
+    // split factors (NC / 2) | cepstral table] then one region per wave: [raw PCM bytes | GT work areas]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *lwL = reinterpret_cast<T *>(smem);
-    const int lwN = MELM ? a.melSteps * 64 : NC + 8;
+    const int lwN = a.melSteps * 64;
     cpx<T> *winL = reinterpret_cast<cpx<T> *>(lwL + lwN);
     cpx<T> *twL = winL + NZ * G;
     cpx<T> *swL = twL + 15 * 16;
@@ -227,56 +157,32 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
     T *areasW = reinterpret_cast<T *>(region) + a.rowPitch; // (rowPitch: elements reserved for the raw bytes)
     T *Zt = areasW + grp * ZP;
     cpx<T> *Zc = reinterpret_cast<cpx<T> *>(Zt);
-    // power values of the lane's frame, bin order: its own work area, or (MELM) 8 elements into
-    // the wave's areas and PP apart, so that the four frames' values at one bin sit 8 banks apart
-    T *Pw = MELM ? areasW + 8 + grp * PP : Zt;
+    // power values of the lane's frame, bin order: 8 elements into the wave's areas and PP apart,
+    // so that the four frames' values at one bin sit 8 banks apart
+    T *Pw = areasW + 8 + grp * PP;
 
-    if constexpr (MELM) {
-        for (int i = tid; i < lwN; i += WAVES * 64) lwL[i] = a.melW64[i];
-    } else {
-        for (int i = tid; i < NC + 8; i += WAVES * 64) lwL[i] = i < NC ? a.loWt[i] : (T)0;
-    }
-    if constexpr (TABLDS) {
-        for (int i = tid; i < NZ * G; i += WAVES * 64) winL[i] = reinterpret_cast<const cpx<T> *>(a.window)[i];
-        for (int i = tid; i < 15 * 16; i += WAVES * 64) twL[i] = reinterpret_cast<const cpx<T> *>(a.tw)[i];
-        for (int i = tid; i < NC / 2; i += WAVES * 64) swL[i] = reinterpret_cast<const cpx<T> *>(a.splitTw)[i];
-        for (int i = tid; i < a.dctElems; i += WAVES * 64) dctL[i] = a.dctT[i];
-    }
+    for (int i = tid; i < lwN; i += WAVES * 64) lwL[i] = a.melW64[i];
+    for (int i = tid; i < NZ * G; i += WAVES * 64) winL[i] = reinterpret_cast<const cpx<T> *>(a.window)[i];
+    for (int i = tid; i < 15 * 16; i += WAVES * 64) twL[i] = reinterpret_cast<const cpx<T> *>(a.tw)[i];
+    for (int i = tid; i < NC / 2; i += WAVES * 64) swL[i] = reinterpret_cast<const cpx<T> *>(a.splitTw)[i];
+    for (int i = tid; i < a.dctElems; i += WAVES * 64) dctL[i] = a.dctT[i];
     // every value a masked sum may read from a work area is a finite number from here on
     for (int i = tt; i < GT * ZP; i += 64) areasW[i] = (T)0;
     __syncthreads();
-    const cpx<T> *winT = TABLDS ? winL : reinterpret_cast<const cpx<T> *>(a.window);
-    const cpx<T> *twT = TABLDS ? twL : reinterpret_cast<const cpx<T> *>(a.tw);
-    const cpx<T> *swT = TABLDS ? swL : reinterpret_cast<const cpx<T> *>(a.splitTw);
-    const T *dctT = TABLDS ? dctL : a.dctT;
+    const cpx<T> *winT = winL, *twT = twL, *swT = swL;
+    const T *dctT = dctL;
 
-    // !MELM: mel segment parts of the lane and the part ranges of its channels; MELM: per slot of
-    // the matrix-core filterbank, where the lane reads its power operand (element offset into the
-    // wave's areas) and which channel its result belongs to (see the pipe64 tables, api.cpp)
-    const int4 *lseg = reinterpret_cast<const int4 *>(a.laneSeg);
-    int partB[NPL], partE[NPL];
-    int4 chanParts[CHL];
+    // Per slot of the matrix-core filterbank: where the lane reads its power operand (element offset
+    // into the wave's areas) and which channel its result belongs to (see the pipe64 tables, api.cpp)
     int melOff[4], melChan[4];
-    if constexpr (MELM) {
+    {
         const int4 m0 = reinterpret_cast<const int4 *>(a.melMeta)[2 * tt], m1 = reinterpret_cast<const int4 *>(a.melMeta)[2 * tt + 1];
         melOff[0] = m0.x, melChan[0] = m0.y, melOff[1] = m0.z, melChan[1] = m0.w;
         melOff[2] = m1.x, melChan[2] = m1.y, melOff[3] = m1.z, melChan[3] = m1.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int4 e = lseg[l + G * j];
-            partB[j] = e.x;
-            partE[j] = e.z >= 0 ? e.y : e.x;
-        }
-#pragma unroll
-        for (int j = 0; j < CHL; ++j) {
-            const int ch = l + G * j;
-            chanParts[j] = ch < a.P ? lseg[kPipeParts + ch] : make_int4(0, 0, 0, 0);
-        }
     }
     const T preK = a.preK;
     const int JW = a.M + a.c0Flag;
-    const int F_V = CH == 1 ? 1 : a.V, F_S = a.S;
+    const int F_S = a.S;
     const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
 
     // The wave's stream of tiles: chunks of a.tilesPerTeam consecutive tiles, the first one by the
@@ -369,15 +275,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
             }
         }
     };
-    // One byte read per 128-byte line of a tile's bytes, so that its fetch finds them in L2.
-    unsigned warm0 = 0, warm1 = 0;
-    auto warm = [&](const PipeTile &t) {
-        const long long off0 = max(t.src() - BPI, 0ll), last = a.planEnd - 1;
-        const int nb = tile_bytes(t);
-        if (tt * 128 < nb) warm0 = a.pcm[min(off0 + tt * 128, last)];
-        if ((tt + 64) * 128 < nb) warm1 = a.pcm[min(off0 + (tt + 64) * 128, last)];
-    };
-
     {
         u4u pf0[PFN];
         fetch(cur, pf0);
@@ -385,7 +282,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         wave_fence();
     }
 
-    T lvr[4] = {0, 0, 0, 0}; // log-mel values of the lane's channels: [channel slot] (G = 16) or [row] (G = 64)
+    T lvr[4] = {0, 0, 0, 0}; // log-mel values of the lane's channels, per channel slot
 
     // One (frame, row) round.  LAST: the tile's last row.
     auto round = [&](const int vv, auto lastTag) {
@@ -396,19 +293,14 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         const bool firstTile = cur.first();
         T *fo = a.out + ((long long)cur.outRow + fr) * a.step + vv * a.D;
         const bool live = grp < nf;
-        // (tables read through L1: the lane index is made opaque once per round, so that what derives
-        // from it is recomputed here instead of being hoisted out of the tile loop and spilled)
-        int lq = l;
-        if constexpr (!TABLDS) asm volatile("" : "+v"(lq));
+        const int lq = l;
         STAMP(0);
-        if constexpr (LAST && EARLY) {
+        // the next tile's bytes are requested at the start of the round
+        if constexpr (LAST) {
             if (nx.valid()) {
                 draw_step();
                 fetch(nx, pf);
             }
-        }
-        if constexpr (!EARLY) {
-            if (vv == 0 && nx.valid()) warm(nx);
         }
 
         // ---- the lane's sample pairs (2n, 2n+1), n = l + G r, of derived row vv from the raw bytes
@@ -417,49 +309,19 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         //      samples (main.c:227), Hamming window (main.c:229), frame energy (mfcc.c:138-142)
         cpx<T> v[PPL];
         int zcn = 0;
-        if constexpr (G == 64) {
-            const unsigned *rawLane = raw + 3 * l;
-            const cpx<T> *winLane = winT + lq;
-            switch (vv) { // (the same for every lane)
-            case 0: pipe_expand_wide<NZ, ZCT, 0>(v, zcn, rawLane, l, winLane, preK, firstTile, a.wlen); break;
-            case 1: pipe_expand_wide<NZ, ZCT, 1>(v, zcn, rawLane, l, winLane, preK, firstTile, a.wlen); break;
-            case 2: pipe_expand_wide<NZ, ZCT, 2>(v, zcn, rawLane, l, winLane, preK, firstTile, a.wlen); break;
-            default: pipe_expand_wide<NZ, ZCT, 3>(v, zcn, rawLane, l, winLane, preK, firstTile, a.wlen); break;
-            }
-        } else
         {
             // instants 2n-1 (predecessor), 2n, 2n+1, 2n+2 start at byte (frame start + 2n) BPI
-            const unsigned *src = raw + (CH == 1 ? ((fr * a.inc) >> 1) + l : 3 * l);
+            const unsigned *src = raw + ((fr * a.inc) >> 1) + l;
 #pragma unroll
             for (int r = 0; r < NZ; ++r) {
                 unsigned d[DW];
-                if constexpr (G == 16) {
-                    d[0] = src[G * r];
-                    d[1] = src[G * r + 1];
-                } else {
-                    const u4u q = *reinterpret_cast<const u4u *>(src + 3 * G * r);
-                    const u2u q2 = *reinterpret_cast<const u2u *>(src + 3 * G * r + 4);
-                    d[0] = q.x, d[1] = q.y, d[2] = q.z, d[3] = q.w, d[4] = q2.x, d[5] = q2.y;
-                }
+                d[0] = src[G * r];
+                d[1] = src[G * r + 1];
                 T x[4];
-                if constexpr (CH == 1) {
-                    x[0] = (T)(int)(short)(d[0] & 0xffffu);
-                    x[1] = (T)((int)d[0] >> 16);
-                    x[2] = (T)(int)(short)(d[1] & 0xffffu);
-                    x[3] = (T)((int)d[1] >> 16);
-                } else {
-                    int cL[4], cR[4];
-                    cL[0] = window_sample<3, 0, DW>(d), cR[0] = window_sample<3, 3, DW>(d);
-                    cL[1] = window_sample<3, 6, DW>(d), cR[1] = window_sample<3, 9, DW>(d);
-                    cL[2] = window_sample<3, 12, DW>(d), cR[2] = window_sample<3, 15, DW>(d);
-                    cL[3] = window_sample<3, 18, DW>(d), cR[3] = window_sample<3, 21, DW>(d);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        // (the integer sum and difference of two 24-bit samples are exact)
-                        const int c = vv == 0 ? cL[i] : (vv == 1 ? cR[i] : (vv == 2 ? cL[i] + cR[i] : cL[i] - cR[i]));
-                        x[i] = vv == 2 ? (T)0.5 * (T)c : (T)c;
-                    }
-                }
+                x[0] = (T)(int)(short)(d[0] & 0xffffu);
+                x[1] = (T)((int)d[0] >> 16);
+                x[2] = (T)(int)(short)(d[1] & 0xffffu);
+                x[3] = (T)((int)d[1] >> 16);
                 T y1 = sub_mul_exact(x[1], x[0], preK);
                 const T y2 = sub_mul_exact(x[2], x[1], preK);
                 if (r == 0 && firstTile && fr == 0 && l == 0) y1 = x[1] * ((T)1 - preK); // s[1] *= 1 - k
@@ -484,11 +346,11 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
             for (int r = 0; r < NZ; ++r) e2 += v[r] * v[r];
             te = frame_sum<G>((T)4 * (e2.x + e2.y)); // (the window table holds half the Hamming values)
         }
-        if (G == 16 && a.zcFlag) zcn = frame_sum<G>(zcn); // (1024-point class: counted over the wave already)
+        if (a.zcFlag) zcn = frame_sum<G>(zcn);
         STAMP(1);
 
         // ---- NC-point complex FFT of z[n] = x[2n] + i x[2n+1] (Realft mfcc.c:262-270): Stockham
-        //      stages of radix 16, 16 (and 4), real parts and imaginary parts exchanged in turn
+        //      stages of radix 16 and 16, real parts and imaginary parts exchanged in turn
         Radix<T, 16>::run(v);
         {
             T *wp = Zt + 17 * l;                                 // zpad(16 l + r) = 17 l + r
@@ -510,35 +372,8 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
 #pragma unroll
         for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], twT[(r - 1) * 16 + (lq & 15)]); // sub-transform size 16: [r-1][l mod 16]
         Radix<T, 16>::run(v);
-        if constexpr (G == 64) {
-            const int o = ((l >> 4) << 8) + (l & 15);
-            T *wp = Zt + o + (o >> 4);                           // zpad(o + 16 r) = zpad(o) + 17 r
-            const T *rp = Zt + l + (l >> 4);                     // zpad(l + 64 b + 256 r) = zpad(l) + 68 b + 272 r
-#pragma unroll
-            for (int r = 0; r < 16; ++r) wp[17 * r] = v[r].x;
-            wave_fence();
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * b + r].x = rp[68 * b + 272 * r];
-            wave_fence();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) wp[17 * r] = v[r].y;
-            wave_fence();
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * b + r].y = rp[68 * b + 272 * r];
-            wave_fence();
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 1; r < 4; ++r) v[4 * b + r] = cmul(v[4 * b + r], twT[15 * 16 + (r - 1) * 256 + 64 * b + lq]); // size 256: [r-1][l + 64 b]
-#pragma unroll
-            for (int b = 0; b < 4; ++b) Radix<T, 4>::run(&v[4 * b]);
-        }
         // the lane now holds X[l + G m], m = 0 .. 15, in register xr(m)
-        auto xr = [&](int m) -> cpx<T> & { return G == 16 ? v[m] : v[4 * (m & 3) + (m >> 2)]; };
+        auto xr = [&](int m) -> cpx<T> & { return v[m]; };
         STAMP(3);
 
         // ---- real-FFT split and power (mfcc.c:274-290, ek of mfcc.c:153-155): the upper half of the
@@ -571,12 +406,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         }
         wave_fence();
         STAMP(4);
-        if constexpr (LAST && !EARLY) {
-            if (nx.valid()) {
-                draw_step();
-                fetch(nx, pf);
-            }
-        }
 
         // ---- sub-band energies / brightness (main.c:235-236): every band (the whole spectrum when
         //      only the brightness is asked for) gets a power-of-two share of the frame's lanes
@@ -586,27 +415,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
             while (lpb * 2 * nseg <= G) lpb *= 2;
             const int b = l / lpb, sl = l & (lpb - 1);
             T e = 0, ek = 0;
-            if (G == 64 && (nseg & (nseg - 1)) == 0) {
-                // Bands of a power-of-two width lie a multiple of the banks' span apart: the lanes of
-                // band b start lpb b bins into it and wrap around, so that the bands' simultaneous
-                // reads fall into different banks (the sums only change their order).
-                const int lo = b * width, rot = sl + lpb * b, steps = width / lpb; // (steps >= 16: nseg <= 8 here, else one lane per band)
-                for (int i0 = 0; i0 < steps; i0 += 8) {
-                    T pv[8];
-                    int kk[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        kk[i] = lo + ((rot + (i0 + i) * lpb) & (width - 1));
-                        pv[i] = Pw[kk[i]];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const bool in = i0 + i < steps;
-                        e += in ? pv[i] : (T)0;
-                        ek += in ? (T)(kk[i] + 1) * pv[i] : (T)0;
-                    }
-                }
-            } else if (b < nseg) {
+            if (b < nseg) {
                 const int lo = b * width, hi = (b == nseg - 1) ? NC : lo + width;
                 for (int k = lo + sl; k < hi; k += 4 * lpb) { // four reads in flight
                     T pv[4];
@@ -638,12 +447,9 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         }
         STAMP(5);
 
-        // ---- mel filterbank (mfcc.c:152-163): the bins whose lower channel is c form one segment,
-        //      cut by the host into parts; a lane sums Tc = sum loWt p and Uc = sum (p - loWt p) of its
-        //      parts in bin order, the part sums go to the work area, and the lane of channel b adds the
-        //      parts of U[b-1] and of T[b] in part (= bin) order; then log(max(., 1)) (mfcc.c:171-176)
-        if constexpr (MELM) {
-            // matrix-core form: 4 x 4 x 4 products (frame x channel of a quad x bin), four quads at a
+        // ---- mel filterbank (mfcc.c:152-163) on the matrix cores, then log(max(., 1)) (mfcc.c:171-176)
+        {
+            // 4 x 4 x 4 products (frame x channel of a quad x bin), four quads at a
             // time (one per block of 16 result lanes ... see the table builder); lane (j, blk, k) =
             // (lane % 4, lane / 4 % 4, lane / 16) feeds the power of frame j at the block's bin
             // r0 + 4 t + k and the weight of that bin for channel j of the block's quad, and receives
@@ -682,65 +488,6 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
                     tbase += L;
                 }
             }
-        } else {
-        T ps[NPL][2];
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            T accT = 0, accU = 0;
-            for (int k = partB[j]; k < partE[j]; k += 4) {
-                T pv[4], wv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    pv[i] = Zt[k + i]; // (reads past the part stay inside the area / the weight table's zero tail)
-                    wv[i] = lwL[k + i];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool in = k + i < partE[j];
-                    const T t1 = wv[i] * pv[i];
-                    accT += in ? t1 : (T)0;
-                    accU += in ? pv[i] - t1 : (T)0;
-                }
-            }
-            ps[j][0] = accT;
-            ps[j][1] = accU;
-        }
-        wave_fence(); // every part has been read: the bins' place takes the part sums
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            Zt[l + G * j] = ps[j][0];
-            Zt[kPipeParts + l + G * j] = ps[j][1];
-        }
-        wave_fence();
-#pragma unroll
-        for (int j = 0; j < CHL; ++j) {
-            const int ch = l + G * j;
-            const int4 cp = chanParts[j];
-            T pu[10], pt[10];
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                pu[i] = Zt[kPipeParts + cp.x + i];
-                pt[i] = Zt[cp.z + i];
-            }
-            T mu = 0, mt = 0;
-#pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                mu += i < cp.y ? pu[i] : (T)0;
-                mt += i < cp.w ? pt[i] : (T)0;
-            }
-            const T m = mu + mt;
-            const T lv = fast_log(m < (T)1 ? (T)1 : m);
-            if (ch < a.P) {
-                if (a.fbankFlag) {
-                    if (live) fo[ch] = lv;
-                } else {
-                    lvr[0] = vv == 0 ? lv : lvr[0];
-                    lvr[1] = vv == 1 ? lv : lvr[1];
-                    lvr[2] = vv == 2 ? lv : lvr[2];
-                    lvr[3] = vv == 3 ? lv : lvr[3];
-                }
-            }
-        }
         }
         wave_fence(); // the work area is free again
         STAMP(6);
@@ -753,16 +500,9 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
                 //      coefficient j of every row from its table row (row M is all ones: C0)
                 auto cepstra = [&](auto rowsTag) {
                     constexpr int VV = decltype(rowsTag)::value;
-                    if constexpr (MELM) {
 #pragma unroll
-                        for (int sl = 0; sl < 4; ++sl)
-                            if (melChan[sl] >= 0 && a.melSlotSteps[sl] > 0) Zt[melChan[sl]] = lvr[sl];
-                    } else {
-                        if (l < a.P) {
-#pragma unroll
-                            for (int vq = 0; vq < VV; ++vq) Zt[l * VV + vq] = lvr[vq];
-                        }
-                    }
+                    for (int sl = 0; sl < 4; ++sl)
+                        if (melChan[sl] >= 0 && a.melSlotSteps[sl] > 0) Zt[melChan[sl]] = lvr[sl];
                     wave_fence();
                     T *orow = a.out + ((long long)cur.outRow + fr) * a.step;
                     for (int j0 = 0; j0 < JW; j0 += G) {
@@ -791,12 +531,7 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
                         }
                     }
                 };
-                switch (F_V) {
-                case 1: cepstra(std::integral_constant<int, 1>{}); break;
-                case 2: cepstra(std::integral_constant<int, 2>{}); break;
-                case 3: cepstra(std::integral_constant<int, 3>{}); break;
-                default: cepstra(std::integral_constant<int, 4>{}); break;
-                }
+                cepstra(std::integral_constant<int, 1>{}); // (mono input: one derived row)
             }
             wave_fence(); // the raw bytes are in place, the work area is free
         }
@@ -806,14 +541,12 @@ __global__ __launch_bounds__(kPipeWaves * 64) void k_pipe64(const FrontArgs<doub
         // the descriptor three tiles ahead: asked for now, moved into place at the tile's end
         const int id3 = next_tile_s();
         const PipeTile d3 = pipe_desc(tab, id3 < 0 ? 0 : id3, id3 >= 0);
-        for (int vv = 0; vv + 1 < F_V; ++vv) round(vv, std::false_type{});
-        round(F_V - 1, std::true_type{});
+        round(0, std::true_type{}); // (mono input: one derived row per frame)
         if (!nx.valid()) break;
         cur = nx;
         nx = nn;
         nn = d3;
     }
-    asm volatile("" ::"v"(warm0), "v"(warm1));
     finish();
     STAMP_FLUSH;
 }
@@ -1399,7 +1132,9 @@ int pipe64_class(int log2nc, int channels, int bps, int wlen, int inc)
     if (log2nc == 10 && channels == 2 && bps == 3 && wlen > 1024 && wlen <= 2048) return 10;
     return 0;
 }
-int pipe64_waves(int cls) { return cls == 8 ? kPipeWaves : kPipeWideWaves; }
+// waves per workgroup: the 256-point class takes 12 (three per SIMD) when `fits12` says that 12
+// regions fit the LDS beside the tables, else 8
+int pipe64_waves(int cls, bool fits12) { return cls == 8 ? (fits12 ? 12 : kPipeWaves) : kPipeWideWaves; }
 int pipe64_frames_per_tile(int cls) { return cls == 8 ? 4 : 1; }
 int pipe64_lanes(int cls) { return cls == 8 ? 16 : 64; }
 int pipe64_nz(int cls, int wlen)
@@ -1433,13 +1168,13 @@ int pipe64_tab_elems(int cls, int wlen, int dctElems, int melSteps)
 // bytes from a frame's first instant that the 1024-point class's loads reach (12 per sample pair)
 int pipe64_reach_bytes(int wlen) { return 12 * 64 * pipe64_nz(10, wlen); }
 
-template <int LOG2NC, int CH, int BPS, int NZ, bool ZCT>
+template <int NZ, int WAVES>
 static int launch_pipe_t(const FrontArgs<double> &a, int numBlocks, size_t lds, hipStream_t st)
 {
     static std::atomic<bool> attrSet[kAttrDevices];
-    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_pipe64<LOG2NC, CH, BPS, NZ, ZCT>), attrSet);
+    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_pipe64<NZ, WAVES>), attrSet);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_pipe64<LOG2NC, CH, BPS, NZ, ZCT>), dim3(numBlocks), dim3(kPipeWaves * 64), lds, st, a);
+    hipLaunchKernelGGL((k_pipe64<NZ, WAVES>), dim3(numBlocks), dim3(WAVES * 64), lds, st, a);
     return (int)hipGetLastError();
 }
 
@@ -1453,11 +1188,14 @@ static int launch_pipew_t(const FrontArgs<double> &a, int numBlocks, size_t lds,
     return (int)hipGetLastError();
 }
 
-int launch_pipe64(const FrontArgs<double> &a, int cls, int numBlocks, size_t lds, void *stream)
+int launch_pipe64(const FrontArgs<double> &a, int cls, int waves, int numBlocks, size_t lds, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nz = pipe64_nz(cls, a.wlen);
-    if (cls == 8) return nz == 13 ? launch_pipe_t<8, 1, 2, 13, false>(a, numBlocks, lds, st) : launch_pipe_t<8, 1, 2, 16, false>(a, numBlocks, lds, st);
+    if (cls == 8) {
+        if (waves == 12) return nz == 13 ? launch_pipe_t<13, 12>(a, numBlocks, lds, st) : launch_pipe_t<16, 12>(a, numBlocks, lds, st);
+        return nz == 13 ? launch_pipe_t<13, 8>(a, numBlocks, lds, st) : launch_pipe_t<16, 8>(a, numBlocks, lds, st);
+    }
     if (a.zcFlag) return nz == 14 ? launch_pipew_t<14, true>(a, numBlocks, lds, st) : launch_pipew_t<16, true>(a, numBlocks, lds, st);
     return nz == 14 ? launch_pipew_t<14, false>(a, numBlocks, lds, st) : launch_pipew_t<16, false>(a, numBlocks, lds, st);
 }
