@@ -1045,6 +1045,7 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
         // ---- the next round's samples, then this round's results (row layout main.c:241-249)
         fix_raw(LAST && nx.valid() ? nx : cur, own, pred);
         to_samples(LAST ? 0 : vv + 1, own, pred);
+        STAMP(7);
         if (bandAt >= 0) fo[bandAt] = bandOut;
         if (l == 0) {
             if (a.brightFlag) fo[a.M + a.c0Flag + a.energyFlag + a.zcFlag] = brightOut;
@@ -1052,6 +1053,7 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
             if (a.zcFlag) fo[a.M + a.c0Flag + a.energyFlag] = (T)zcn / (T)(a.wlen - 1);        // main.c:244
         }
         if (a.fbankFlag && l < a.P) fo[l] = lv;
+        STAMP(8);
         if constexpr (LAST) {
             if (!a.fbankFlag) {
                 // ---- cepstra (FBank2MFCC mfcc.c:180-195) and C0 (FBank2C0 mfcc.c:197-208): the frame's
