@@ -372,7 +372,7 @@ def main():
             bound = "hbm (nominal: no counter pass of this workload and precision is committed)"
         roofline = {"bound": bound, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                    "kernel": "static-feature kernel (f32: k_lean256 c2, c3; k_wide1024 c1, c4, c5; f64: k_pipe64)",
+                    "kernel": "static-feature kernel (f32: k_lean256 c2, c3; k_wide1024 c1, c4, c5; f64: k_pipe64 c2, c3; k_pipe64w c1, c4, c5)",
                     "kernel_ms": kavg * 1e3,
                     "algorithmic_bytes_per_frame": kernel_bytes,
                     "algorithmic_flop_per_frame": flops,

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_pipe64(const FrontArgs<double> a
 // to per-bin values, turns them into that row's integer samples just before its own results go
 // out, and carries those to the next round -- so no round starts by waiting for memory behind the
 // stores of the one before it.  LDS: [filterbank weights | window pairs | the lanes' mel part
-// tables | cepstral table when there is room] shared, then one work area per wave.
+// tables | run slots | cepstral table when there is room] shared, then one work area per wave.
 // ------------------------------------------------------------------------------------------
 namespace {
 
@@ -659,7 +659,8 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
     T *lwL = reinterpret_cast<T *>(smem);
     cpx<T> *winL = reinterpret_cast<cpx<T> *>(lwL + NC + 8);
     int4 *segL = reinterpret_cast<int4 *>(winL + NZ * G);
-    T *dctL = reinterpret_cast<T *>(segL + kPipeParts + 64);
+    int *combCtr = reinterpret_cast<int *>(segL + kPipeParts + 64); // the next comb of the workgroup's sequence to be claimed
+    T *dctL = reinterpret_cast<T *>(segL + kPipeParts + 64 + 1);
     const bool dctInLds = a.rowPitch > 0; // (rowPitch: elements of the table's copy)
     T *Zt = reinterpret_cast<T *>(smem) + a.tabElems + (size_t)wave * a.teamElems;
     cpx<T> *Zc = reinterpret_cast<cpx<T> *>(Zt);
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
     for (int i = tid; i < NC + 8; i += WAVES * 64) lwL[i] = i < NC ? a.loWt[i] : (T)0;
     for (int i = tid; i < NZ * G; i += WAVES * 64) winL[i] = reinterpret_cast<const cpx<T> *>(a.window)[i];
     for (int i = tid; i < kPipeParts + 64; i += WAVES * 64) segL[i] = reinterpret_cast<const int4 *>(a.laneSeg)[i];
+    if (tid == 0) *combCtr = WAVES; // (wave w starts on comb w)
     if (dctInLds) {
         for (int i = tid; i < a.dctElems; i += WAVES * 64) dctL[i] = a.dctT[i];
     }
@@ -683,51 +685,36 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
     const int F_V = a.V, F_S = a.S;
     const int subAt = a.M + a.c0Flag + a.energyFlag + a.zcFlag + a.brightFlag;
 
-    // The wave's stream of tiles (chunks drawn from a.work, as in k_pipe64).
-    const int teamId = blockIdx.x * WAVES + wave, numTeams = gridDim.x * WAVES, C = a.tilesPerTeam;
-    int chunkBase = teamId * C, chunkPos = 0, nextBase = 0;
-    bool haveNext = false, needDraw = true;
-    auto draw = [&]() {
-        unsigned drawn = 0;
-        if (tt == 0) drawn = atomicAdd(a.work, 1u);
-        nextBase = (sgpr((int)drawn) + numTeams) * C;
-        haveNext = true;
-        needDraw = false;
-    };
+    // The workgroup's stream of tiles: runs of WAVES x C consecutive frames, run r of workgroup b
+    // being run b + r gridDim.x of the launch; comb k mod WAVES of such a run is its frames k mod
+    // WAVES, k mod WAVES + WAVES, ...  A wave starts on the comb of its own index and claims every
+    // further comb from a counter in LDS when it has used up the one before: the waves of a
+    // workgroup work on neighbouring frames at about the same time -- the bytes consecutive frames
+    // share are fetched once and found in L2 by the others -- and none of them ever waits for
+    // another.  A claimed comb whose first frame lies behind the last tile ends the wave's stream
+    // (every later comb starts further on).
+    const int C = a.tilesPerTeam;
+    int chunkBase = wave, chunkPos = 0; // (comb index in the workgroup's sequence, position in it)
+    auto comb_first = [&](int k) { return ((long long)blockIdx.x + (long long)(k / WAVES) * gridDim.x) * (WAVES * C) + k % WAVES; };
     auto next_tile = [&]() {
         if (chunkPos == C) {
-            if (!haveNext) {
-                if (!needDraw) return -1;
-                draw();
-            }
-            chunkBase = nextBase;
+            int k = 0;
+            if (tt == 0) k = atomicAdd(combCtr, 1);
+            chunkBase = sgpr(k);
             chunkPos = 0;
-            haveNext = false;
-            needDraw = chunkBase < a.numTiles;
         }
-        const int id = chunkBase + chunkPos;
+        const long long id = comb_first(chunkBase) + WAVES * chunkPos;
         if (id >= a.numTiles) return -1;
         ++chunkPos;
-        return id;
-    };
-    auto draw_step = [&]() {
-        if (needDraw && !haveNext) draw();
+        return (int)id;
     };
     auto next_tile_s = [&]() {
         const int id = sgpr(next_tile());
         chunkBase = sgpr(chunkBase);
         chunkPos = sgpr(chunkPos);
-        nextBase = sgpr(nextBase);
         return id;
     };
-    auto finish = [&]() {
-        __threadfence();
-        if (tt == 0 && atomicInc(a.work + 1, (unsigned)numTeams - 1u) == (unsigned)numTeams - 1u) {
-            __hip_atomic_store(a.work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    if (chunkBase >= a.numTiles) {
-        finish();
+    if (comb_first(chunkBase) >= a.numTiles) {
         STAMP_FLUSH;
         return;
     }
@@ -917,7 +904,6 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
         // ---- the bytes of the round to come (this frame's next row, or the next frame's first)
         unsigned own[NZ][3], pred[2];
         if constexpr (LAST) {
-            if (nx.valid()) draw_step();
             load_raw(nx.valid() ? nx : cur, own, pred); // (behind the last frame: this one's again, unused)
         } else {
             load_raw(cur, own, pred);
@@ -1115,7 +1101,6 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
         nx = nn;
         nn = d3;
     }
-    finish();
     STAMP_FLUSH;
 }
 
@@ -1164,7 +1149,7 @@ int pipe64_tab_elems(int cls, int wlen, int dctElems, int melSteps)
     const int nc = 1 << cls;
     int n = cls == 8 ? melSteps * 64 : nc + 8;
     if (cls == 8) n += 2 * (pipe64_nz(cls, wlen) * 16 + 15 * 16 + nc / 2) + dctElems;
-    else n += 2 * pipe64_nz(cls, wlen) * 64 + (kPipeParts + 64) * 2;
+    else n += 2 * pipe64_nz(cls, wlen) * 64 + (kPipeParts + 64) * 2 + 2; // (+ the run slots)
     return (n + 1) & ~1;
 }
 // bytes from a frame's first instant that the 1024-point class's loads reach (12 per sample pair)

@@ -6,16 +6,17 @@
 // brightness / sub-bands main.c:235-236, FBank2MFCC / FBank2C0 mfcc.c:180-208, row layout
 // main.c:241-249), organised like the 256-point kernel of lean256.hip:
 //   - a wave is a team of its own: one (frame, row) at a time, 64 lanes x 16 points, three FFT
-//     stages (16 x 16 x 4) with wave-level synchronisation only; 8 waves per workgroup, one
-//     workgroup per CU;
-//   - a tile is one frame.  What a wave keeps of it in LDS is the RAW interleaved PCM bytes (6 bytes
-//     per instant for every row together) instead of one single-precision row per derived row:
-//     10.4 KB instead of 14 - 28 KB, which is what lets 8 waves share a CU.  Every (frame, row)
-//     round expands the three instants a lane needs per point pair straight from those bytes;
-//   - the next frame's bytes are requested (16-byte vectors into registers) once the FFT of the
-//     frame's last row has freed its registers and stored over the current ones before that
-//     round's results go out; frames at the first or last bytes of the buffer are patched byte by
-//     byte;
+//     stages (16 x 16 x 4) with wave-level synchronisation only; 12 waves per workgroup (three per
+//     SIMD, 168 registers), one workgroup per CU;
+//   - a tile is one frame, and nothing of its raw bytes is kept in LDS: a round asks for the next
+//     round's bytes straight from memory (one 12-byte load per sample pair: a wave's load is 768
+//     consecutive bytes; the 2.3-fold overlap of consecutive frames is served by L2) once its
+//     spectrum has been reduced to per-bin values, turns them into that row's samples just before
+//     its own results go out, and carries those samples to the next round -- no round starts by
+//     waiting for memory behind the stores of the one before it;
+//   - what a round needs at its very start (window pairs) and the lanes' mel part tables sit in
+//     LDS, shared by the workgroup; twiddle, split and filterbank factors are read through L1 in
+//     the middle of a round;
 //   - waves draw chunks of consecutive frames from a shared counter (see lean256.hip).
 #include <hip/hip_runtime.h>
 
@@ -304,14 +305,15 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     const int tt0 = tid & 63;
     int tt = tt0, l = tt0;
 
-    // LDS: [window pairs | the lanes' mel part tables | cepstral table (when there is room; rows of
-    // P + 1 elements)] shared by the workgroup, then one region per wave: [work area | log-mel rows
+    // LDS: [window pairs | the lanes' mel part tables | run slots | cepstral table (when there is room;
+    // rows of P + 1 elements)] shared by the workgroup, then one region per wave: [work area | log-mel rows
     // of the frame]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kWinElems = 2 * G * NZ, kSegElems = 3 * 64 * 4;
     cpx<T> *winL = reinterpret_cast<cpx<T> *>(smem);
     int4 *segL = reinterpret_cast<int4 *>(smem + kWinElems * sizeof(T));
-    T *dctL = reinterpret_cast<T *>(smem) + kWinElems + kSegElems;
+    int *combCtr = reinterpret_cast<int *>(segL + 3 * 64); // the next comb of the workgroup's sequence to be claimed
+    T *dctL = reinterpret_cast<T *>(smem) + kWinElems + kSegElems + 4;
     const bool dctInLds = a.rowPitch > 0; // (rowPitch: elements of the table's copy)
     unsigned char *region = smem + ((size_t)a.tabElems + (size_t)wave * a.teamElems) * sizeof(T);
     T *Zt = reinterpret_cast<T *>(region);
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     for (int i = tid; i < G * NZ; i += WAVES * 64) winL[i] = reinterpret_cast<const cpx<T> *>(a.window)[i];
     // mel segment parts of the lanes (round 0 and 1) and the part ranges of the lanes' channels
     for (int i = tid; i < 3 * 64; i += WAVES * 64) segL[i] = reinterpret_cast<const int4 *>(a.laneSeg)[i];
+    if (tid == 0) *combCtr = WAVES; // (wave w starts on comb w)
     if (dctInLds) {
         const int rows = a.M + a.c0Flag, pitch = a.tabPitch;
         for (int i = tid; i < rows * pitch; i += WAVES * 64) {
@@ -346,51 +349,36 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
     const int JW = a.M + a.c0Flag;
     const int F_V = a.V, F_S = a.S;
 
-    // The wave's stream of tiles (chunks drawn from a.work, see lean256.hip).
-    const int teamId = blockIdx.x * WAVES + wave, numTeams = gridDim.x * WAVES, C = a.tilesPerTeam;
-    int chunkBase = teamId * C, chunkPos = 0, nextBase = 0;
-    bool haveNext = false, needDraw = true;
-    auto draw = [&]() {
-        unsigned drawn = 0;
-        if (tt == 0) drawn = atomicAdd(a.work, 1u);
-        nextBase = (sgpr((int)drawn) + numTeams) * C;
-        haveNext = true;
-        needDraw = false;
-    };
+    // The workgroup's stream of tiles: runs of WAVES x C consecutive frames, run r of workgroup b
+    // being run b + r gridDim.x of the launch; comb k mod WAVES of such a run is its frames k mod
+    // WAVES, k mod WAVES + WAVES, ...  A wave starts on the comb of its own index and claims every
+    // further comb from a counter in LDS when it has used up the one before: the waves of a
+    // workgroup work on neighbouring frames at about the same time -- the bytes consecutive frames
+    // share are fetched once and found in L2 by the others -- and none of them ever waits for
+    // another.  A claimed comb whose first frame lies behind the last tile ends the wave's stream
+    // (every later comb starts further on).
+    const int C = a.tilesPerTeam;
+    int chunkBase = wave, chunkPos = 0; // (comb index in the workgroup's sequence, position in it)
+    auto comb_first = [&](int k) { return ((long long)blockIdx.x + (long long)(k / WAVES) * gridDim.x) * (WAVES * C) + k % WAVES; };
     auto next_tile = [&]() {
         if (chunkPos == C) {
-            if (!haveNext) {
-                if (!needDraw) return -1;
-                draw();
-            }
-            chunkBase = nextBase;
+            int k = 0;
+            if (tt == 0) k = atomicAdd(combCtr, 1);
+            chunkBase = sgpr(k);
             chunkPos = 0;
-            haveNext = false;
-            needDraw = chunkBase < a.numTiles;
         }
-        const int id = chunkBase + chunkPos;
+        const long long id = comb_first(chunkBase) + WAVES * chunkPos;
         if (id >= a.numTiles) return -1;
         ++chunkPos;
-        return id;
-    };
-    auto draw_step = [&]() {
-        if (needDraw && !haveNext) draw();
+        return (int)id;
     };
     auto next_tile_s = [&]() {
         const int id = sgpr(next_tile());
         chunkBase = sgpr(chunkBase);
         chunkPos = sgpr(chunkPos);
-        nextBase = sgpr(nextBase);
         return id;
     };
-    auto finish = [&]() {
-        __threadfence();
-        if (tt == 0 && atomicInc(a.work + 1, (unsigned)numTeams - 1u) == (unsigned)numTeams - 1u) {
-            __hip_atomic_store(a.work, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    if (chunkBase >= a.numTiles) {
-        finish();
+    if (comb_first(chunkBase) >= a.numTiles) {
         STAMP_FLUSH;
         return;
     }
@@ -650,7 +638,6 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             // ---- the bytes of the round to come (this frame's next row, or the next frame's first)
             unsigned own[NZ][3], pred[2];
             if constexpr (LAST) {
-                if (nx.valid()) draw_step();
                 load_raw(nx.valid() ? nx : cur, own, pred); // (behind the last frame: this one's again, unused)
             } else {
                 load_raw(cur, own, pred);
@@ -805,15 +792,14 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
         nx = nn;
         nn = d3;
     }
-    finish();
     STAMP_FLUSH;
 }
 
 // Geometry the host plans with.
 int wide1024_nz(int wlen) { return (wlen + 127) / 128; }
 int wide1024_waves() { return kWideWaves; }
-// elements of the LDS part the waves share in front of the cepstral table: window pairs, mel part tables
-int wide1024_shared_elems(int wlen) { return 2 * 64 * (wide1024_nz(wlen) == 14 ? 14 : 16) + 3 * 64 * 4; }
+// elements of the LDS part the waves share in front of the cepstral table: window pairs, mel part tables, run slots
+int wide1024_shared_elems(int wlen) { return 2 * 64 * (wide1024_nz(wlen) == 14 ? 14 : 16) + 3 * 64 * 4 + 4; }
 // bytes from a frame's first instant that the kernel's loads reach (12 per sample pair, 64 x NZ pairs)
 int wide1024_reach_bytes(int wlen) { return 12 * 64 * (wide1024_nz(wlen) == 14 ? 14 : 16); }
 
