@@ -179,6 +179,22 @@ def test_stereo_2048_point_kernel_modes(oracle, wlen, bank, vec, cepstral, extra
             _compare(g, ref, kw, f64)
 
 
+def test_stereo_2048_point_kernels_with_the_largest_cepstral_table(oracle):
+    """64 channels, 64 coefficients + C0, four rows: the double-precision kernel's cepstral table no
+    longer fits the LDS beside twelve work areas and is read from memory; the single-precision
+    kernel's still fits."""
+    kw = dict(sampleRate=44100, lowpassfre=-1, hipassfre=-1, preemphasise=0.97, wlen=2048, inc=1024, vecNum=4,
+              fbankFlag=0, bankNum=64, MFCCNum=64, MFCC0thFlag=1, energyFlag=1, zeroCrossingFlag=1, brightFlag=1,
+              subBandEFlag=8)
+    pcms = [_pcm(2048 + 1024 * k + 5, 2, 3, 700 + k, 44100, tone=0) for k in (7, 2)]
+    refs = [oracle.extract_pcm_bytes(oracle.make_config(**kw), p, 2, 3) for p in pcms]
+    for f64 in (False, True):
+        cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+        got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 2, 3, pad=5)
+        for g, ref in zip(got, refs):
+            _compare(g, ref, kw, f64)
+
+
 @pytest.mark.parametrize("wlen,inc", [(1025, 1), (1025, 342), (1765, 441), (2047, 700), (2048, 512), (1764, 882)])
 def test_stereo_frames_at_the_first_and_last_bytes_of_the_buffer(oracle, wlen, inc):
     """The 24-bit stereo kernels read a frame's bytes straight from the buffer: a frame whose last
