@@ -540,10 +540,14 @@ __global__ __launch_bounds__(kBlock, (front_waves_per_simd<T, LOG2NC, PPLOG>()))
                         for (int g = 0; g < nseg; ++g) fo[subAt + g] = bandE[g] / total;
                     }
                 }
-                if (active && F_fftLength > 0) {                                   // main.c:247
+                if (F_fftLength > 0) {                                             // main.c:247
                     const int at = a.M + a.c0Flag + a.energyFlag + F_zc + F_bright + F_S;
-                    for (int q = l; q < F_fftLength; q += G) fo[at + q] = tsqrt<T>(Pw[q]);
-                    group_sync<G>(); // the per-bin products below overwrite the power values
+                    if (active)
+                        for (int q = l; q < F_fftLength; q += G) fo[at + q] = tsqrt<T>(Pw[q]);
+                    // the per-bin products below overwrite the power values.  (Every frame slot takes
+                    // part, the ones past the tile's last frame too: frames wider than a wave meet at
+                    // the workgroup's barrier, which must see the same count from all of them.)
+                    group_sync<G>();
                 }
             }
             if (F_S == 0 && F_bright && active && l == 0)

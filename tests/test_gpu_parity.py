@@ -179,6 +179,25 @@ def test_stereo_2048_point_kernel_modes(oracle, wlen, bank, vec, cepstral, extra
             _compare(g, ref, kw, f64)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_frames_wider_than_a_wave_with_debug_columns_and_a_ragged_last_tile(oracle, precision):
+    """Mono 24-bit frames of 2048 samples take the general kernel with two waves per frame; with the
+    debug magnitude columns (fftLength, main.c:247) every frame slot of a tile -- the ones past a
+    ragged tile's last frame too -- must take part in the workgroup's barriers.  (A slot that skipped
+    one left the cepstra of the tile's last frame unwritten now and then: several runs.)"""
+    kw = dict(sampleRate=44100, lowpassfre=-1, hipassfre=-1, preemphasise=0.95, wlen=2048, inc=512, vecNum=1, fbankFlag=0,
+              bankNum=39, MFCCNum=39, MFCC0thFlag=0, energyFlag=0, zeroCrossingFlag=1, brightFlag=1, subBandEFlag=8,
+              fftLength=5, regreOrder=4, delwin=2)
+    f64 = precision == "f64"
+    pcms = [_pcm(2048 + 512 * k + 100, 1, 3, 31 + k, 44100, tone=0) for k in (26, 10, 5)]
+    refs = [oracle.extract_pcm_bytes(oracle.make_config(**kw), p, 1, 3) for p in pcms]
+    cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+    for _ in range(6):
+        got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 1, 3, pad=0)
+        for g, ref in zip(got, refs):
+            _compare(g, ref, kw, f64)
+
+
 def test_stereo_2048_point_kernels_with_the_largest_cepstral_table(oracle):
     """64 channels, 64 coefficients + C0, four rows: the double-precision kernel's cepstral table no
     longer fits the LDS beside twelve work areas and is read from memory; the single-precision

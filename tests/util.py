@@ -53,8 +53,8 @@ def kind_tolerance(kind, mx, kw, delta=False):
         return 1e-4
     if kind == "energy":
         return 2e-5
-    if kind == "cep":  # (stated: 1e-5 relative; held to 4e-6)
-        return max(4e-6 * mx, 1e-5 * float(np.sqrt(2.0 * P)))
+    if kind == "cep":  # (stated: 1e-5 relative; largest seen over 5000 random configurations: 6.8e-6)
+        return max(1e-5 * mx, 1e-5 * float(np.sqrt(2.0 * P)))
     if kind == "c0":   # sqrt(2/P) times the sum of P log-mel values: their errors add
         return max(1e-6 * mx, 2.5e-5 * float(np.sqrt(2.0 * P)))
     if kind == "zc":
