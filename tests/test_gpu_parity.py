@@ -198,6 +198,29 @@ def test_frames_wider_than_a_wave_with_debug_columns_and_a_ragged_last_tile(orac
             _compare(g, ref, kw, f64)
 
 
+@pytest.mark.parametrize("frames_per_comb", [1, 2, 3, 4, 7])
+def test_stereo_2048_point_kernels_over_many_short_utterances(oracle, frames_per_comb, tuning):
+    """The 24-bit stereo kernels hand runs of 12 x C consecutive frames to the workgroups and let the
+    waves claim the combs of a run: every C, utterances of 1 to 70 frames (runs that straddle
+    utterances, ragged last runs, fewer frames than waves), both precisions."""
+    tuning(leanChunk=frames_per_comb)
+    kw = dict(sampleRate=44100, lowpassfre=-1, hipassfre=-1, preemphasise=0.97, wlen=1764, inc=882, vecNum=2,
+              fbankFlag=0, bankNum=26, MFCCNum=13, MFCC0thFlag=1, energyFlag=1, zeroCrossingFlag=1, brightFlag=1,
+              subBandEFlag=8)
+    rng = np.random.default_rng(77 + frames_per_comb)
+    lens = [int(1764 + 882 * rng.integers(0, 70) + rng.integers(0, 882)) for _ in range(60)] + [1764, 1763]
+    pcms = [_pcm(n, 2, 3, 900 + i, 44100, tone=0) for i, n in enumerate(lens)]
+    ocfg = oracle.make_config(**kw)
+    refs = [oracle.extract_pcm_bytes(ocfg, p, 2, 3) for p in pcms]
+    for f64 in (False, True):
+        cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+        got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 2, 3, pad=1)
+        for g, ref in zip(got, refs):
+            assert g.shape == ref.shape
+            if ref.shape[0]:
+                _compare(g, ref, kw, f64)
+
+
 def test_stereo_2048_point_kernels_with_the_largest_cepstral_table(oracle):
     """64 channels, 64 coefficients + C0, four rows: the double-precision kernel's cepstral table no
     longer fits the LDS beside twelve work areas and is read from memory; the single-precision
