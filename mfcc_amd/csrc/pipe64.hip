@@ -976,7 +976,22 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
             const int4 sg = segL[l + G * j];
             const int pB = sg.x, pE = sg.z >= 0 ? sg.y : sg.x;
             T accT = 0, accU = 0;
-            for (int k = pB; k < pE; k += 4) {
+            int k = pB;
+            for (; k + 4 <= pE; k += 4) { // whole groups of four bins: no bin of them lies past the part
+                T pv[4], wv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pv[i] = Zt[k + i];
+                    wv[i] = lwL[k + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const T t1 = wv[i] * pv[i];
+                    accT += t1;
+                    accU += pv[i] - t1;
+                }
+            }
+            if (k < pE) { // the part's last one to three bins
                 T pv[4], wv[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -984,7 +999,7 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
                     wv[i] = lwL[k + i];
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 3; ++i) {
                     const bool in = k + i < pE;
                     const T t1 = wv[i] * pv[i];
                     accT += in ? t1 : (T)0;
