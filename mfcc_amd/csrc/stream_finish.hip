@@ -208,8 +208,10 @@ __global__ __launch_bounds__(kSegWaves * 64) void k_seg_pass(const StreamArgs<T>
 // Regress's clamped pointers give.  Finished rows of a narrow matrix (one column block) leave
 // through LDS as one contiguous piece written in aligned 16-byte vectors.  Same arithmetic, same
 // results as k_seg_pass.
+// (The single-precision write kernels of windows 1 and 2 fit 128 registers without spills: four
+// waves per SIMD for them; the sums kernels and the others spill there and stay at three.)
 template <typename T, int ORD, int DW, int MODE, bool DIRECT>
-__global__ __launch_bounds__(kSegWaves * 64) void k_seg_reg(const StreamArgs<T> a)
+__global__ __launch_bounds__(kSegWaves * 64, (DW <= 2 && sizeof(T) == 4 && MODE == 1) ? 4 : 1) void k_seg_reg(const StreamArgs<T> a)
 {
     constexpr bool WRITE = MODE == 1, SUMS = MODE == 0;
     constexpr int K = reg_rows(DW), HH = (ORD - 1) * DW, HH1 = ORD == 3 ? DW : 0;
