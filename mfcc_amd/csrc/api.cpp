@@ -629,6 +629,9 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
     // channels ("quad") and a contiguous run of the bins that touch them.  Possible when a frame fills at most a quarter wave
     // (256..1024 complex points at 16 points per lane) and every run fits kMelSteps.
     p->melSteps = 0;
+    int leanSteps = 0; // the same filterbank placed for k_lean256's 8-byte reads
+    std::vector<float> leanW;
+    std::vector<int32_t> leanMeta;
     if (leanCand && pplog == 4 && log2nc >= 8 && log2nc <= 10 && !tune.noMelMatrix) {
         const int P1 = P + 1, NQ = (P + 3) / 4;
         std::vector<int> sb(P1, 0), se(P1, 0);
@@ -686,52 +689,59 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
                 pieces[chainStart[q] + i] = {q, q0[q] + (int)((long)len * i / n), q0[q] + (int)((long)len * (i + 1) / n), i, n};
         }
         // Every block reads `steps` consecutive bins from r0 <= k0 (r0 + steps >= k1, inside the
-        // frame).  The 32 lanes of a half wave (8 blocks x 4 frame slots, slots 8 banks apart)
-        // hit 32 different LDS banks when the 8 blocks' r0 differ modulo 8: take the smallest
-        // `steps` for which such starts exist (first fit, blocks with the fewest possible starts first).
+        // frame).  Rule 0 (k_front: single-word reads, 32 banks, frame slots 8 banks apart): the 32
+        // lanes of a half wave (8 blocks x 4 frame slots) hit 32 different LDS banks when the 8
+        // blocks' r0 differ modulo 8.  Rule 1 (k_lean256: 8-byte reads of two consecutive bins, 64
+        // banks, frame slots 16 banks apart): r0 even and the 8 blocks' r0 / 2 different modulo 8.
+        // Either way the smallest `steps` for which such starts exist wins (first fit, blocks with
+        // the fewest possible starts first); rule 1 falls back to even starts with conflicts.
         int longest = 0;
         for (const Piece &pc : pieces) longest = std::max(longest, pc.k1 - pc.k0);
-        std::vector<int> r0(pieces.size(), 0);
-        int steps = 0;
-        for (int trial = std::max(longest, 1); trial <= std::min(kMelSteps, nc) && part && !steps; ++trial) {
-            std::vector<size_t> order(pieces.size());
-            for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-            auto choices = [&](size_t b) {
-                if (pieces[b].quad < 0) return nc; // an idle block may start anywhere: placed last
-                return std::min(pieces[b].k0, nc - trial) - std::max(0, pieces[b].k1 - trial);
-            };
-            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return choices(x) < choices(y); });
-            char used[2][8] = {{0}};
-            bool ok = true;
-            for (size_t b : order) {
-                const bool idle = pieces[b].quad < 0;
-                const int lo = idle ? 0 : std::max(0, pieces[b].k1 - trial), hi = idle ? std::min(7, nc - trial) : std::min(pieces[b].k0, nc - trial);
-                int pick = -1;
-                for (int r = hi; r >= lo && pick < 0; --r)
-                    if (!used[b / 8][r & 7]) pick = r;
-                if (pick < 0) {
-                    ok = false;
-                    break;
+        auto place = [&](int rule, bool conflictFree, std::vector<int> &r0) {
+            r0.assign(pieces.size(), 0);
+            const int unit = rule ? 2 : 1;
+            for (int trial = std::max(longest, 1); trial <= std::min(kMelSteps, nc) && part; ++trial) {
+                if (rule && (trial & 1)) continue;
+                std::vector<size_t> order(pieces.size());
+                for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+                auto choices = [&](size_t b) {
+                    if (pieces[b].quad < 0) return nc; // an idle block may start anywhere: placed last
+                    return std::min(pieces[b].k0, nc - trial) - std::max(0, pieces[b].k1 - trial);
+                };
+                std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return choices(x) < choices(y); });
+                char used[2][8] = {{0}};
+                bool ok = true;
+                for (size_t b : order) {
+                    const bool idle = pieces[b].quad < 0;
+                    const int lo = idle ? 0 : std::max(0, pieces[b].k1 - trial), hi = idle ? std::min(7 * unit, nc - trial) : std::min(pieces[b].k0, nc - trial);
+                    int pick = -1;
+                    for (int r = hi; r >= lo && pick < 0; --r)
+                        if (r % unit == 0 && (!conflictFree || !used[b / 8][(r / unit) & 7])) pick = r;
+                    if (pick < 0) {
+                        ok = false;
+                        break;
+                    }
+                    used[b / 8][(pick / unit) & 7] = 1;
+                    r0[b] = pick;
                 }
-                used[b / 8][pick & 7] = 1;
-                r0[b] = pick;
+                if (ok) return trial;
             }
-            if (ok) steps = trial;
-        }
-        if (steps >= 1) {
-            p->melSteps = steps;
-            p->melW.assign((size_t)steps * 64, 0.0f);
-            p->melMeta.assign(64 * 4, 0);
-            for (int ln = 0; ln < 64; ++ln) p->melMeta[4 * ln + 2] = -1;
+            return 0;
+        };
+        // tables of one placement: weights [step][lane], per-lane {r0, chain flags, channel, 0}
+        auto build = [&](int steps, const std::vector<int> &r0, std::vector<float> &W, std::vector<int32_t> &meta) {
+            W.assign((size_t)steps * 64, 0.0f);
+            meta.assign(64 * 4, 0);
+            for (int ln = 0; ln < 64; ++ln) meta[4 * ln + 2] = -1;
             for (size_t b = 0; b < pieces.size(); ++b) {
                 const Piece &pc = pieces[b];
                 const bool owner = pc.pos == pc.len - 1;
                 for (int j = 0; j < 4; ++j) {
                     const int ln = 4 * (int)b + j, ch = 4 * pc.quad + j;
-                    p->melMeta[4 * ln + 0] = r0[b];
+                    meta[4 * ln + 0] = r0[b];
                     if (pc.quad < 0) continue;
-                    p->melMeta[4 * ln + 1] = (pc.pos >= 1 ? 1 : 0) | (owner ? 2 : 0) | (pc.pos >= 2 ? 4 : 0) | (pc.pos >= 3 ? 8 : 0);
-                    p->melMeta[4 * ln + 2] = (owner && ch < P) ? ch : -1;
+                    meta[4 * ln + 1] = (pc.pos >= 1 ? 1 : 0) | (owner ? 2 : 0) | (pc.pos >= 2 ? 4 : 0) | (pc.pos >= 3 ? 8 : 0);
+                    meta[4 * ln + 2] = (owner && ch < P) ? ch : -1;
                     if (ch >= P) continue;
                     for (int t = 0; t < steps; ++t) {
                         const int k = r0[b] + t;
@@ -740,9 +750,26 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
                         double w = 0.0;
                         if (sIdx == ch + 1) w = c->tab.loWt[k];
                         if (sIdx == ch) w = 1.0 - c->tab.loWt[k];
-                        p->melW[(size_t)t * 64 + ln] = (float)w;
+                        W[(size_t)t * 64 + ln] = (float)w;
                     }
                 }
+            }
+        };
+        std::vector<int> r0;
+        const int steps = place(0, true, r0);
+        if (steps >= 1) {
+            p->melSteps = steps;
+            build(steps, r0, p->melW, p->melMeta);
+            if (log2nc == 8) {
+                std::vector<int> r1;
+                int stepsL = place(1, true, r1);
+                bool clean = stepsL >= 1;
+                if (!clean) stepsL = place(1, false, r1);
+                if (stepsL >= 1) {
+                    leanSteps = stepsL;
+                    build(stepsL, r1, leanW, leanMeta);
+                }
+                if (tune.debug) fprintf(stderr, "mfcc plan: matrix-core mel with 8-byte reads, %d steps%s\n", stepsL, clean ? "" : " (bank conflicts)");
             }
             // frame slots 8 banks apart: work-area pitch = 8 (mod 32) elements
             zPitch = ((zPitch + 23) & ~31) + 8;
@@ -902,16 +929,18 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
     // the window pairs; a wave's region holds its sample row and four work areas.  12 waves per
     // workgroup when the registers and the LDS allow, else 8; one workgroup per CU.
     p->lean256 = false;
-    if (p->mode == 2 && p->totalRows < 0x7fffffffLL && c->cfg.wlen >= 8 && lean256_applies(log2nc, p->mode, c->cfg.inc, c->cfg.wlen, p->melSteps)) {
+    if (p->mode == 2 && p->totalRows < 0x7fffffffLL && c->cfg.wlen >= 8 && lean256_applies(log2nc, p->mode, c->cfg.inc, c->cfg.wlen, leanSteps)) {
         const int nz = lean256_nz(c->cfg.wlen);
         const int ft = 4;
         const int ninst = (ft - 1) * c->cfg.inc + c->cfg.wlen + 1;
         // the row ends where the last frame's zero-window reads and the last fetched vector end
         const int rowPitchL = (std::max((ft - 1) * c->cfg.inc + 32 * nz, ((ninst + 7) & ~7)) + 3) & ~3;
-        // work area of a frame: its padded complex points only, 8 banks apart
-        const int zl = ((2 * (nc + nc / 16) + 23) & ~31) + 8;
+        // work area of a frame: its padded complex points only; pitch = 48 (mod 64) elements puts the
+        // four frame slots 16 banks apart and the two slots of a half wave 32 banks apart
+        const int zBase = 2 * (nc + nc / 16);
+        const int zl = zBase + ((48 - zBase % 64) + 64) % 64;
         const int teamL = rowPitchL + 4 * zl;
-        const int tabL = (((c->dctElems + 1) & ~1) + lean256_mel_steps(p->melSteps) * 64 + 2 * nz * 16 + nc + 3) & ~3;
+        const int tabL = (((c->dctElems + 1) & ~1) + lean256_mel_steps(leanSteps) * 64 + 2 * nz * 16 + 3) & ~3;
         for (int pass = 0; pass < 2 && !p->lean256; ++pass) {
             if (pass == 0 && tune.leanWaves == 8) continue;
             const int waves = lean256_waves(c->cfg.wlen, pass == 0);
@@ -919,6 +948,9 @@ static int choose_tile(MFCCPlan *p, bool allowWide = true)
             const size_t bytes = ((size_t)tabL + (size_t)waves * teamL) * sizeof(float);
             if (bytes > kLds) continue;
             p->lean256 = true;
+            p->melSteps = leanSteps;
+            p->melW.swap(leanW);
+            p->melMeta.swap(leanMeta);
             p->leanWaves = waves;
             p->framesPerTile = ft;
             p->rowPitch = rowPitchL;

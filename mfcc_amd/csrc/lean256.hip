@@ -61,10 +61,11 @@ __device__ __forceinline__ LeanTile lean_desc(const TileDesc *tab, int idx, bool
     return t;
 }
 
-// Work areas are 8 banks apart (pitch = 8 mod 32), which keeps the mel phase's 8 blocks x 4 slots
-// out of each other's banks; the frame of lane group g uses area slot_of(g) = {0, 2, 1, 3}, so that
-// the two groups whose power values one 32-lane pass stores sit 16 banks apart.  Result r of the
-// mel products therefore belongs to the tile's frame slot_of(r).
+// Work areas are 48 elements apart modulo 64 (slots at banks 0, 48, 32, 16 of the 64 that 8-byte
+// reads see), which keeps the mel phase's 8 blocks x 4 slots out of each other's banks (the host
+// places the blocks' first bins for that); the frame of lane group g uses area slot_of(g) =
+// {0, 2, 1, 3}, so that the two groups of a 32-lane pass sit 32 banks apart and their 128-byte
+// runs never meet.  Result r of the mel products therefore belongs to the tile's frame slot_of(r).
 __device__ __forceinline__ constexpr int slot_of(int g) { return ((g & 1) << 1) | (g >> 1); }
 
 // lane i takes x of lane i + 1; lane 63 takes `last`
@@ -73,18 +74,69 @@ __device__ __forceinline__ unsigned wave_shl1(unsigned x, unsigned last)
     return (unsigned)__builtin_amdgcn_update_dpp((int)last, (int)x, 0x130, 0xf, 0xf, false);
 }
 
+// Operands of the mel products: the power values of two consecutive bins and the weights of two
+// consecutive steps, one ds_read_b64 each (256 B/clk; fused ds_read2 forms move half of that).
+// Group G8 covers steps 8 G8 .. 8 G8 + 7 (the last group of MS steps may be half a group).
+template <int N, int STRIDE, int BASE, int I = 0>
+__device__ __forceinline__ void lean_issue(v2f *t, unsigned addr)
+{
+    if constexpr (I < N) {
+        t[I] = lds_rd64<BASE + I * STRIDE>(addr);
+        lean_issue<N, STRIDE, BASE, I + 1>(t, addr);
+    }
+}
+template <int MS, int G8>
+constexpr int lean_mel_pairs() { return MS - 8 * G8 >= 8 ? 4 : (MS - 8 * G8) / 2; }
+template <int MS, bool WL, int G8>
+__device__ __forceinline__ void lean_mel_issue(v2f *av, v2f *bw, unsigned aAddr, unsigned wAddr)
+{
+    constexpr int N = lean_mel_pairs<MS, G8>();
+    lean_issue<N, 8, 32 * G8>(av, aAddr);
+    if constexpr (WL) lean_issue<N, 512, 2048 * G8>(bw, wAddr);
+}
+// waits until at most K newer LDS operations are outstanding; ties N results to the wait
+template <int K, int N>
+__device__ __forceinline__ void lean_wait(v2f *t)
+{
+    static_assert(N == 2 || N == 4, "pairs per group");
+    if constexpr (N == 4)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : "i"(K));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(t[0]), "+v"(t[1]) : "i"(K));
+}
+// Products of group G8 while the operands of group G8 + 1 are on their way.
+template <int MS, bool TREG, int G8>
+__device__ __forceinline__ void lean_mel_groups(v2f (&av)[2][4], v2f (&bw)[2][4], unsigned aAddr, unsigned wAddr,
+                                                const float *mwreg, Acc4<float> &m1, Acc4<float> &m2)
+{
+    constexpr int MSG = (MS + 7) / 8;
+    if constexpr (G8 < MSG) {
+        constexpr int c = G8 & 1, N = lean_mel_pairs<MS, G8>();
+        constexpr int NEXT = G8 + 1 < MSG ? lean_mel_pairs<MS, G8 + 1>() * (TREG ? 1 : 2) : 0;
+        if constexpr (G8 + 1 < MSG) lean_mel_issue<MS, !TREG, G8 + 1>(av[c ^ 1], bw[c ^ 1], aAddr, wAddr);
+        lean_wait<NEXT, N>(av[c]);
+        if constexpr (!TREG) lean_wait<NEXT, N>(bw[c]);
+#pragma unroll
+        for (int t = 0; t < N; ++t) {
+            m1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c][t].x, TREG ? mwreg[8 * G8 + 2 * t] : bw[c][t].x, m1, 0, 0, 0);
+            m2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c][t].y, TREG ? mwreg[8 * G8 + 2 * t + 1] : bw[c][t].y, m2, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lean_mel_groups<MS, TREG, G8 + 1>(av, bw, aAddr, wAddr, mwreg, m1, m2);
+    }
+}
+
 } // namespace
 
 // NZ: number of first-stage inputs of a lane that can be non-zero, ceil(wlen / 32): 13 for
 // 400-sample frames in 512 points (the zero padding of mfcc.c:144-147 is then never loaded,
-// multiplied or added), 16 otherwise.  WAVES: waves (teams) per workgroup.  MSG: groups of 8 steps
+// multiplied or added), 16 otherwise.  WAVES: waves (teams) per workgroup.  MSQ: groups of 4 steps
 // of the mel filterbank products.
-template <int NZ, int WAVES, int MSG>
+template <int NZ, int WAVES, int MSQ>
 __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a)
 {
     constexpr int NC = kLeanNc, G = kLeanG, PPL = kLeanPpl, GT = kLeanGt, TEAM = 64, NT = WAVES * 64;
-    constexpr int PFN = kLeanPfn, MS = MSG * 8;
-    constexpr bool SWL = WAVES > 8; // three waves per SIMD: the split factors are read from LDS too
+    constexpr int PFN = kLeanPfn, MS = MSQ * 4;
     constexpr bool TREG = WAVES <= 8; // two waves per SIMD: window pairs and mel weights in registers
     typedef float T;
     STAMP_DECL
@@ -93,7 +145,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
     const int wave = sgpr(tid >> 6);
     const int tt = tid & 63, l = tt & (G - 1), grp = tt >> 4;
 
-    // LDS: [cepstral table | mel weights (MS x 64) | window pairs (NZ x 16) | split factors (128)] then one region per
+    // LDS: [cepstral table | mel weights (MS x 64) | window pairs (NZ x 16)] then one region per
     // wave: [sample row | GT work areas (the tile's log-mel rows alias the first in cepstral mode)]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *ldsTab = reinterpret_cast<T *>(smem);
@@ -104,23 +156,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
     T *fbk = zbuf;
 
     for (int i = tid; i < a.dctElems; i += NT) ldsTab[i] = a.dctT[i];
-    for (int i = tid; i < MS * 64; i += NT) melWl[i] = i < a.melSteps * 64 ? a.melW[i] : 0.0f;
+    // (mel weights of two consecutive steps side by side: one 8-byte read per pair of steps)
+    for (int i = tid; i < MS * 64; i += NT) melWl[(i >> 7) * 128 + 2 * (i & 63) + ((i >> 6) & 1)] = i < a.melSteps * 64 ? a.melW[i] : 0.0f;
     for (int i = tid; i < NZ * 16; i += NT) winl[i] = reinterpret_cast<const cpx<T> *>(a.window)[i]; // half the Hamming values
-    cpx<T> *swl = winl + NZ * 16;
-    for (int i = tid; i < NC / 2; i += NT) swl[i] = reinterpret_cast<const cpx<T> *>(a.splitTw)[i];
     // Everything a frame reads from the row is finite from here on: a tile only overwrites it with
     // converted samples, and what lies behind a frame's last sample meets a zero window value.
     for (int s = tt; s < a.rowPitch; s += TEAM) rows[s] = (T)0;
     __syncthreads();
     const T *dctT = ldsTab;
-    const T *melB = melWl + tt;
+    const T *melB = melWl + 2 * tt;
     const cpx<T> *winp = winl + l; // pair r of the lane: winp[16 r]
 
     // Per-lane constants in registers: split factors, second-stage twiddles.
     cpx<T> swreg[PPL / 2];
     cpx<T> twr[fft_twiddle_regs<8, 4>()];
 #pragma unroll
-    for (int q = 0; q < PPL / 2; ++q) swreg[q] = SWL ? cpx<T>{0, 0} : reinterpret_cast<const cpx<T> *>(a.splitTw)[l + G * q];
+    for (int q = 0; q < PPL / 2; ++q) swreg[q] = reinterpret_cast<const cpx<T> *>(a.splitTw)[l + G * q];
     fft_load_twiddles<T, 8, 4>(twr, l, reinterpret_cast<const cpx<T> *>(a.tw));
     cpx<T> wreg[TREG ? NZ : 1];
     float mwreg[TREG ? MS : 1];
@@ -339,7 +390,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
             // ---- real-FFT split and power (mfcc.c:274-290, ek of mfcc.c:153-155): Z[256 - k] for
             //      k = l + 16 q is register 15 - q of lane 16 - l (register 16 - q of lane 0 itself)
             T pa[PPL / 2], pb[PPL / 2];
-            if constexpr (SWL) lds_read_strided<PPL / 2, 128>(swreg, swl + l);
             {
                 // the upper half of the lane's points goes through the (free) work area, complex
                 // index = bin; the lane reads back Z[256 - l - 16 q], q = 7 .. 0 (lane 0, q = 0: one
@@ -373,30 +423,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
             // ---- mel filterbank (mfcc.c:152-163) as 4 x 4 x 1 matrix-core products: block b = 4
             //      lanes owns 4 consecutive channels and a run of bins; lane (b, i) feeds the power
             //      of frame slot i at bin r0_b + t and the weight of that bin for channel 4 q_b + i
-            //      (loads of 8 steps run a group ahead of the products that use them)
-            float av[2][8], bw[2][8];
+            //      (operands of 8 steps run a group ahead of the products that use them)
+            v2f av[2][4], bw[2][4];
             Acc4<float> macc = {0, 0, 0, 0}, macc2 = {0, 0, 0, 0};
-            auto mel_load = [&](int c, int g) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    av[c][t] = melA[8 * g + t];
-                    if constexpr (!TREG) bw[c][t] = melB[(8 * g + t) * 64];
-                }
-            };
-            auto mel_mac = [&](int c, int g) {
-#pragma unroll
-                for (int t = 0; t < 8; t += 2) {
-                    macc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c][t], TREG ? mwreg[8 * g + t] : bw[c][t], macc, 0, 0, 0);
-                    macc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c][t + 1], TREG ? mwreg[8 * g + t + 1] : bw[c][t + 1], macc2, 0, 0, 0);
-                }
-            };
-            mel_load(0, 0);
-#pragma unroll
-            for (int g = 0; g < MSG; ++g) {
-                if (g + 1 < MSG) mel_load((g + 1) & 1, g + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mel_mac(g & 1, g);
-            }
+            lean_mel_issue<MS, !TREG, 0>(av[0], bw[0], lds_addr(melA), lds_addr(melB));
+            lean_mel_groups<MS, TREG, 0>(av, bw, lds_addr(melA), lds_addr(melB), mwreg, macc, macc2);
             macc += macc2;
             STAMP(5);
             {
@@ -468,7 +499,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_lean256(const FrontArgs<float> a
 // LDS), one workgroup per CU.
 int lean256_nz(int wlen) { return wlen <= 2 * 16 * 13 ? 13 : 16; }
 int lean256_waves(int wlen, bool fits12) { return (lean256_nz(wlen) == 13 && fits12) ? 12 : 8; }
-int lean256_mel_steps(int melSteps) { return ((melSteps + 7) / 8) * 8; }
+// (instantiated for 8, 16, 24, 28 and 32 steps)
+int lean256_mel_steps(int melSteps) { return melSteps <= 24 ? ((melSteps + 7) / 8) * 8 : ((melSteps + 3) / 4) * 4; }
 
 bool lean256_applies(int log2nc, int mode, int inc, int wlen, int melSteps)
 {
@@ -477,24 +509,25 @@ bool lean256_applies(int log2nc, int mode, int inc, int wlen, int melSteps)
     return log2nc == 8 && mode == 2 && vecs <= kLeanPfn * 64 && melSteps >= 1 && melSteps <= kMelSteps;
 }
 
-template <int NZ, int WAVES, int MSG>
+template <int NZ, int WAVES, int MSQ>
 static int launch_lean_t(const FrontArgs<float> &a, int numBlocks, size_t lds, hipStream_t st)
 {
     static std::atomic<bool> attrSet[kAttrDevices];
-    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_lean256<NZ, WAVES, MSG>), attrSet);
+    const hipError_t e = lds_limit_once(reinterpret_cast<const void *>(&k_lean256<NZ, WAVES, MSQ>), attrSet);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_lean256<NZ, WAVES, MSG>), dim3(numBlocks), dim3(WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((k_lean256<NZ, WAVES, MSQ>), dim3(numBlocks), dim3(WAVES * 64), lds, st, a);
     return (int)hipGetLastError();
 }
 
 template <int NZ, int WAVES>
 static int launch_lean_w(const FrontArgs<float> &a, int numBlocks, size_t lds, hipStream_t st)
 {
-    switch ((a.melSteps + 7) / 8) {
-    case 1: return launch_lean_t<NZ, WAVES, 1>(a, numBlocks, lds, st);
+    switch (lean256_mel_steps(a.melSteps) / 4) {
     case 2: return launch_lean_t<NZ, WAVES, 2>(a, numBlocks, lds, st);
-    case 3: return launch_lean_t<NZ, WAVES, 3>(a, numBlocks, lds, st);
-    default: return launch_lean_t<NZ, WAVES, 4>(a, numBlocks, lds, st);
+    case 4: return launch_lean_t<NZ, WAVES, 4>(a, numBlocks, lds, st);
+    case 6: return launch_lean_t<NZ, WAVES, 6>(a, numBlocks, lds, st);
+    case 7: return launch_lean_t<NZ, WAVES, 7>(a, numBlocks, lds, st);
+    default: return launch_lean_t<NZ, WAVES, 8>(a, numBlocks, lds, st);
     }
 }
 
