@@ -223,7 +223,7 @@ __device__ __forceinline__ void wide_fft(cpx<float> (&v)[kWidePpl], cpx<float> *
     for (int r = 1; r < 16; ++r) twB[r - 1] = (twt + (r - 1) * 16)[lu & 15u]; // sub-transform size 16: [r-1][l mod 16]
     Radix<T, 16>::run(v);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Z[zpad(16 * l + r)] = v[r];
+    for (int r = 0; r < 16; ++r) (Z + 17 * l)[r] = v[r]; // zpad(16 l + r) = 17 l + r
     group_sync<G>();
     lds_read_strided<16, (64 + 4) * 8>(v, &Z[zpad(l)]);
 #pragma unroll
@@ -237,12 +237,13 @@ __device__ __forceinline__ void wide_fft(cpx<float> (&v)[kWidePpl], cpx<float> *
     Radix<T, 16>::run(v);
     {
         const int o = ((l >> 4) << 8) + (l & 15);
+        cpx<T> *wp = Z + zpad(o); // zpad(o + 16 r) = zpad(o) + 17 r
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Z[zpad(o + r * 16)] = v[r];
+        for (int r = 0; r < 16; ++r) wp[17 * r] = v[r];
     }
     group_sync<G>();
 #pragma unroll
-    for (int b = 0; b < 4; ++b) lds_read_strided<4, (256 + 16) * 8>(&v[4 * b], &Z[zpad(l + 64 * b)]);
+    for (int b = 0; b < 4; ++b) lds_read_strided<4, (256 + 16) * 8>(&v[4 * b], Z + zpad(l) + 68 * b); // zpad(l + 64 b) = zpad(l) + 68 b
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -253,7 +254,7 @@ __device__ __forceinline__ void wide_fft(cpx<float> (&v)[kWidePpl], cpx<float> *
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Z[zpad(l + 64 * b + r * 256)] = v[4 * b + r];
+        for (int r = 0; r < 4; ++r) (Z + zpad(l))[68 * b + 272 * r] = v[4 * b + r]; // zpad(l + 64 b + 256 r)
     group_sync<G>();
 }
 
@@ -262,7 +263,7 @@ __device__ __forceinline__ void wide_fft(cpx<float> (&v)[kWidePpl], cpx<float> *
 // l >= 1, W = 16 / S; lane 0 holds bins 64 q and 1024 - 64 q (512 for q = 0).  e[b] = sum of the
 // band's powers, ek[b] = sum of (bin + 1) x power, over the lane's 16 bins.
 template <int S>
-__device__ __forceinline__ void wide_bands(const float (&pa)[8], const float (&pb)[8], int l, float (&e)[16], float (&ek)[16])
+__device__ __forceinline__ void wide_bands(const float (&pa)[8], const float (&pb)[8], int l, float (&e)[S], float (&ek)[S])
 {
     constexpr int W = 16 / S, NC = kWideNc, G = kWideG;
 #pragma unroll
@@ -286,6 +287,41 @@ __device__ __forceinline__ void wide_bands(const float (&pa)[8], const float (&p
             ek[bLane0 < S ? bLane0 : S - 1] += l == 0 ? w2 : 0.0f;
         }
     }
+}
+
+// Totals of the S bands over the frame's 64 lanes, through the (free) work area Pw: rows 0 .. S-1
+// hold the lanes' e, rows S .. 2S-1 their ek, [row][lane] with rows of 64 + 4 (the reads then spread
+// over the banks).  Lane (i, j) = (l % 2S, l / 2S) adds lanes 2S j .. 2S j + 2S - 1 of row i, lane
+// exchanges add the 32 / S column groups: lanes with l % 2S < S end with the band totals of e, the
+// others of a row of 2S lanes with those of ek.
+template <int S>
+__device__ __forceinline__ float wide_band_totals(const float (&pa)[8], const float (&pb)[8], int l, float *Pw)
+{
+    constexpr int R = 2 * S, NV = R / 4, G = kWideG;
+    float e[S], ek[S];
+    wide_bands<S>(pa, pb, l, e, ek);
+#pragma unroll
+    for (int g = 0; g < S; ++g) {
+        Pw[g * 68 + l] = e[g];
+        Pw[(S + g) * 68 + l] = ek[g];
+    }
+    group_sync<G>();
+    const float4 *q4 = reinterpret_cast<const float4 *>(Pw + (l % R) * 68 + (l / R) * R);
+    float4 sv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sv[i] = q4[i];
+    float part[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) part[i] = (sv[i].x + sv[i].y) + (sv[i].z + sv[i].w);
+#pragma unroll
+    for (int n = NV; n > 1; n >>= 1)
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) part[i] = part[2 * i] + part[2 * i + 1];
+    float tot = part[0];
+#pragma unroll
+    for (int o = R; o < 64; o <<= 1) tot += __shfl_xor(tot, o, 64);
+    group_sync<G>();
+    return tot;
 }
 
 } // namespace
@@ -550,40 +586,23 @@ __global__ __launch_bounds__(kWideWaves * 64) void k_wide1024(const FrontArgs<fl
             const bool bandsFromRegs = F_S == 2 || F_S == 4 || F_S == 8 || F_S == 16;
             T bandOut = 0, brightOut = 0; // (stored with the round's other results, at its end)
             if (bandsFromRegs) {
-                float e[16], ek[16];
-#pragma unroll
-                for (int g = 0; g < 16; ++g) e[g] = 0.0f, ek[g] = 0.0f;
-                if (F_S == 8) wide_bands<8>(pa, pb, l, e, ek);
-                else if (F_S == 4) wide_bands<4>(pa, pb, l, e, ek);
-                else if (F_S == 2) wide_bands<2>(pa, pb, l, e, ek);
-                else wide_bands<16>(pa, pb, l, e, ek);
-                // the 64 lanes' partial sums through the (free) work area, [value i][lane]
-                // (both kinds at once: rows 0 .. 15 hold e, rows 16 .. 31 ek; lane (i, j) = (l % 32, l / 32)
-                // adds the lanes 32 j .. 32 j + 31 of row i, one lane exchange adds the two halves:
-                // lanes 0 .. 15 end with the totals of e, lanes 16 .. 31 with those of ek)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    Pw[g * 68 + l] = e[g]; // (rows of 64 + 4: the reads below then spread over the banks)
-                    Pw[(16 + g) * 68 + l] = ek[g];
+                T tot, totals;
+                if (F_S == 8) {
+                    tot = wide_band_totals<8>(pa, pb, l, Pw);
+                    totals = group_sum<T, 8>(tot, nullptr, tt);
+                } else if (F_S == 4) {
+                    tot = wide_band_totals<4>(pa, pb, l, Pw);
+                    totals = group_sum<T, 4>(tot, nullptr, tt);
+                } else if (F_S == 2) {
+                    tot = wide_band_totals<2>(pa, pb, l, Pw);
+                    totals = group_sum<T, 2>(tot, nullptr, tt);
+                } else {
+                    tot = wide_band_totals<16>(pa, pb, l, Pw);
+                    totals = group_sum<T, 16>(tot, nullptr, tt);
                 }
-                group_sync<G>();
-                T tot = 0;
-                {
-                    const float4 *q4 = reinterpret_cast<const float4 *>(Pw + (l & 31) * 68 + (l >> 5) * 32);
-                    float4 sv[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) sv[i] = q4[i];
-                    T part[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) part[i] = (sv[i].x + sv[i].y) + (sv[i].z + sv[i].w);
-                    tot = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-                    tot += __shfl_xor(tot, 32, 64);
-                }
-                group_sync<G>();
-                // total power (lanes 0 .. 15) and its bin-weighted sum (lanes 16 .. 31): over the bands,
-                // i.e. over lanes 0 .. S-1 of a row of 16
-                const T totals = group_sum<T, 16>((l & 15) < F_S ? tot : (T)0, nullptr, tt);
-                const T num = __shfl(totals, 16, 64);
+                // total power (lanes 0 .. S-1) and its bin-weighted sum (lanes S .. 2S-1): sums over
+                // aligned runs of S lanes
+                const T num = __shfl(totals, F_S, 64);
                 bandOut = tot / totals;
                 brightOut = num / totals / (T)NC;
             } else if (F_S > 0) {

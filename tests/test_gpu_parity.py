@@ -179,6 +179,24 @@ def test_stereo_2048_point_kernel_modes(oracle, wlen, bank, vec, cepstral, extra
             _compare(g, ref, kw, f64)
 
 
+@pytest.mark.parametrize("bands", [1, 2, 3, 4, 8, 16, 32])
+def test_stereo_2048_point_kernels_every_kind_of_sub_band_count(oracle, bands):
+    """Sub-band energies and brightness (main.c:235-236) in the 24-bit stereo kernels: band counts
+    whose bands are whole strides of a lane's bins (2, 4, 8, 16: summed from registers, one code
+    path per count) and the others (summed from the spectrum in the work area), both precisions."""
+    kw = dict(sampleRate=44100, lowpassfre=-1, hipassfre=-1, preemphasise=0.97, wlen=1764, inc=882, vecNum=2,
+              fbankFlag=1, bankNum=26, MFCCNum=13, MFCC0thFlag=0, energyFlag=1, zeroCrossingFlag=1, brightFlag=1,
+              subBandEFlag=bands)
+    pcms = [_pcm(1764 + 882 * k + 11, 2, 3, 1200 + bands + k, 44100, tone=0) for k in (13, 2, 0)]
+    ocfg = oracle.make_config(**kw)
+    refs = [oracle.extract_pcm_bytes(ocfg, p, 2, 3) for p in pcms]
+    for f64 in (False, True):
+        cfg = ma.make_config(precision=ma.PREC_F64 if f64 else ma.PREC_F32, **kw)
+        got = run_product_batch(ma, cfg, [p.tobytes() for p in pcms], 2, 3, pad=2)
+        for g, ref in zip(got, refs):
+            _compare(g, ref, kw, f64)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f64"])
 def test_frames_wider_than_a_wave_with_debug_columns_and_a_ragged_last_tile(oracle, precision):
     """Mono 24-bit frames of 2048 samples take the general kernel with two waves per frame; with the
