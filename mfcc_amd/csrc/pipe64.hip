@@ -113,15 +113,6 @@ __device__ __forceinline__ double frame_sum(double v)
 template <int G>
 __device__ __forceinline__ int frame_sum(int v) { return group_sum<int, G>(v, nullptr, 0); }
 
-// lane i takes x of lane i + 1; lane 63 takes `last`
-__device__ __forceinline__ double wave_shl1d(double x, double last)
-{
-    const long long xb = __double_as_longlong(x), lb = __double_as_longlong(last);
-    const int lo = __builtin_amdgcn_update_dpp((int)lb, (int)xb, 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp((int)(lb >> 32), (int)(xb >> 32), 0x130, 0xf, 0xf, false);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
-
 } // namespace
 
 // 256-point class (mono 16-bit, frames of at most 512 samples): four frames per wave.  NZ:
@@ -595,20 +586,22 @@ __device__ __forceinline__ void pipew_samples(int (&xa)[NZ], int (&xb)[NZ], int 
 }
 
 // The lane's points (2n, 2n+1), n = l + 64 r, of the frame's row from its integer samples xa[r] =
-// x[2n], xb[r] = x[2n+1] (pred0: the sample in front of the frame; row 2 holds L + R, and `scale`
-// = 0.5 then goes into the window values: scaling by a power of two commutes with every rounding
-// here).  The predecessor 2n-1 of a pair is the second sample of the previous lane's pair (of lane
+// x[2n], xb[r] = x[2n+1] (pred0: the sample in front of the frame; row 2 holds L + R = twice the mid
+// row: the factor goes through the whole frame -- scaling by a power of two commutes with every
+// rounding here -- and comes off the frame energy and the channel sums as 1/4; the sub-band shares
+// and the brightness are ratios).  The predecessor 2n-1 of a pair is the second sample of the previous lane's pair (of lane
 // 63's previous pair for lane 0): one lane shift.  Pre-emphasis over the whole signal in double
 // with separately rounded product and difference (PreEmphasise main.c:208; first-sample rule for
 // the signal's first sample), Hamming window (main.c:229, pairs from winL); with ZC the zero
 // crossings of the un-windowed samples (main.c:227), counted over the wave with mask popcounts
 // (sample 2n+2 is the next lane's first sample).
 template <int NZ, bool ZC>
-__device__ __forceinline__ void pipew_expand(cpx<double> (&v)[16], int &zc, const int (&xa)[NZ], const int (&xb)[NZ], int pred0, double scale,
+__device__ __forceinline__ void pipew_expand(cpx<double> (&v)[16], int &zc, const int (&xa)[NZ], const int (&xb)[NZ], int pred0,
                                              int l, const cpx<double> *winL, double preK, bool firstTile, int wlen)
 {
     constexpr int G = 64;
-    double nextFirst0 = 0; // sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r)
+    typedef unsigned long long u64;
+    u64 nextNeg = 0, nextPos = 0; // sign of sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r), bit 63
 #pragma unroll
     for (int r = NZ - 1; r >= 0; --r) {
         int carry = pred0;
@@ -618,19 +611,31 @@ __device__ __forceinline__ void pipew_expand(cpx<double> (&v)[16], int &zc, cons
         const double y2 = sub_mul_exact(x2, x1, preK);
         if (firstTile && l == 0 && r == 0) y1 = x1 * (1.0 - preK); // s[1] *= 1 - k
         if constexpr (ZC) {
-            const double x3 = wave_shl1d(y1, nextFirst0);
-            // (opposite signs = negative product; the samples are far from the underflow range)
-            bool c01 = y1 * y2 < 0.0, c12 = y2 * x3 < 0.0;
-            // pairs inside the frame only (an instance serves every window length up to 128 NZ)
-            const int s0 = 2 * (l + G * r);
-            c01 = c01 && s0 + 1 < wlen;
-            c12 = c12 && s0 + 2 < wlen;
-            zc += __builtin_popcountll(__builtin_amdgcn_ballot_w64(c01)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c12));
-            const long long yb = __double_as_longlong(y1);
-            nextFirst0 = __longlong_as_double(((long long)sgpr((int)(yb >> 32)) << 32) | (unsigned)sgpr((int)yb));
+            // A crossing = neighbours of opposite signs (the reference's negative product; the samples
+            // are far from the underflow range).  The signs go to lane masks, so the neighbour in the
+            // next lane is a shift of the mask and everything behind the compares is scalar work.
+            const u64 n1 = __builtin_amdgcn_ballot_w64(y1 < 0.0), p1 = __builtin_amdgcn_ballot_w64(y1 > 0.0);
+            const u64 n2 = __builtin_amdgcn_ballot_w64(y2 < 0.0), p2 = __builtin_amdgcn_ballot_w64(y2 > 0.0);
+            const u64 n3 = (n1 >> 1) | nextNeg, p3 = (p1 >> 1) | nextPos; // sample 2n + 2: the next lane's first
+            u64 c01 = (n1 & p2) | (p1 & n2), c12 = (n2 & p3) | (p2 & n3);
+            // pairs inside the frame only (an instance serves every window length from 1025 up to
+            // 128 NZ: rows 0 .. 7 lie inside every such frame): lanes with 2 (l + 64 r) + 1 < wlen
+            // for c01, + 2 for c12
+            if (r >= 8) {
+                const int w = wlen - 2 * G * r;
+                const int k01 = min(max(w >> 1, 0), 64), k12 = min(max((w - 1) >> 1, 0), 64);
+                c01 &= k01 >= 64 ? ~0ull : (1ull << k01) - 1ull;
+                c12 &= k12 >= 64 ? ~0ull : (1ull << k12) - 1ull;
+            }
+            zc += __builtin_popcountll(c01) + __builtin_popcountll(c12);
+            nextNeg = n1 << 63;
+            nextPos = p1 << 63;
+            // (the count is taken here, while the masks are at hand: left to its own schedule the compiler
+            // parks every row's masks in spill lanes and counts at the round's end)
+            asm volatile("" : "+s"(zc), "+s"(nextNeg), "+s"(nextPos));
         }
         const cpx<double> w = winL[l + G * r];
-        v[r] = cpx<double>{y1 * (w.x * scale), y2 * (w.y * scale)};
+        v[r] = cpx<double>{y1 * w.x, y2 * w.y};
     }
 #pragma unroll
     for (int r = NZ; r < 16; ++r) v[r] = cpx<double>{0.0, 0.0};
@@ -805,7 +810,8 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
         //      (mfcc.c:138-142)
         cpx<T> v[PPL];
         int zcn = 0;
-        pipew_expand<NZ, ZCT>(v, zcn, xa, xb, pred0, vv == 2 ? 0.5 : 1.0, l, winL, preK, firstTile, a.wlen);
+        const T pscale = vv == 2 ? (T)0.25 : (T)1; // (row 2 runs on L + R: powers come out fourfold)
+        pipew_expand<NZ, ZCT>(v, zcn, xa, xb, pred0, l, winL, preK, firstTile, a.wlen);
         T te = 0;
         if (a.energyFlag) {
             cpx<T> e2 = {0, 0};
@@ -963,7 +969,7 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
             if (F_S > 0 && head) bandOut = e / total, bandAt = subAt + b;
             brightOut = num / total / (T)NC;
         }
-        const T teOut = a.energyFlag ? fast_log(te) : (T)0;
+        const T teOut = a.energyFlag ? fast_log(te * pscale) : (T)0;
         STAMP(5);
 
         // ---- mel filterbank (mfcc.c:152-163): the bins whose lower channel is c form one segment,
@@ -1031,7 +1037,7 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
                 mu += i < cp.y ? pu[i] : (T)0;
                 mt += i < cp.w ? pt[i] : (T)0;
             }
-            const T m = mu + mt;
+            const T m = (mu + mt) * pscale;
             lv = fast_log(m < (T)1 ? (T)1 : m);
             if (l < a.P && !a.fbankFlag) {
                 lvr[0] = vv == 0 ? lv : lvr[0];
