@@ -152,6 +152,21 @@ def test_lean_kernel_modes(oracle, wlen, bank, cepstral):
         _compare(got, ref, kw, f64)
 
 
+@pytest.mark.parametrize("bank,lo,hi", [(10, 60, 7600), (52, 60, 7600), (15, 60, 7600), (17, -1, -1), (45, -1, -1)])
+def test_lean_kernel_filterbanks_without_a_conflict_free_block_placement(oracle, bank, lo, hi):
+    """The pipelined 256-point kernel reads its mel operands two bins at a time, so every block of
+    the matrix-core filterbank must start on an even bin: filterbanks whose blocks then cannot all
+    sit on different LDS banks (placed with conflicts), and filterbanks whose longest block fills
+    the 32 steps from an odd bin (no placement: the general kernel takes the plan)."""
+    kw = dict(sampleRate=16000, lowpassfre=lo, hipassfre=hi, preemphasise=0.97, wlen=400, inc=160, vecNum=1,
+              fbankFlag=1, bankNum=bank, MFCCNum=min(bank, 13), MFCC0thFlag=0, energyFlag=0)
+    pcm = _pcm(400 + 160 * 45 + 3, 1, 2, 500 + bank, 16000, tone=0)
+    ref = oracle.extract_pcm_bytes(oracle.make_config(**kw), pcm, 1, 2)
+    cfg = ma.make_config(precision=ma.PREC_F32, **kw)
+    got = run_product_batch(ma, cfg, [pcm.tobytes()], 1, 2)[0]
+    _compare(got, ref, kw, False)
+
+
 @pytest.mark.parametrize("wlen,bank,vec", [(1025, 8, 1), (1100, 64, 2), (1153, 23, 3), (1500, 40, 4), (1665, 3, 2),
                                            (1764, 26, 4), (1792, 40, 1), (1793, 57, 2), (2000, 12, 3), (2047, 40, 2),
                                            (2048, 64, 4)])
