@@ -103,11 +103,38 @@ __device__ __forceinline__ double fast_log(double x)
 }
 
 // sum over the G lanes of a frame (G = 16: one row of lanes, G = 64: the wave)
+// x + x of the lane a DPP control names (both halves of the double by one lane-exchange move each:
+// no LDS round trip, as a ds_bpermute-based exchange has)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return x + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// sum over the 16 lanes of a row, in every lane of the row
+__device__ __forceinline__ double row_sum_f64(double v)
+{
+    v = dpp_add_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = dpp_add_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = dpp_add_f64<0x141>(v); // row_half_mirror
+    v = dpp_add_f64<0x140>(v); // row_mirror
+    return v;
+}
+__device__ __forceinline__ double lane_value_f64(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 template <int G>
 __device__ __forceinline__ double frame_sum(double v)
 {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    static_assert(G == 16 || G == 64, "a frame is a row of lanes or the wave");
+    v = row_sum_f64(v);
+    if constexpr (G == 64) // the four rows' sums, the same in every lane
+        v = (lane_value_f64(v, 0) + lane_value_f64(v, 16)) + (lane_value_f64(v, 32) + lane_value_f64(v, 48));
     return v;
 }
 template <int G>
@@ -959,10 +986,13 @@ __global__ __launch_bounds__(kPipeWideWaves * 64) void k_pipe64w(const FrontArgs
                     }
                 }
             }
-            for (int o = lpb >> 1; o > 0; o >>= 1) {
-                e += __shfl_xor(e, o, 64);
-                ek += __shfl_xor(ek, o, 64);
-            }
+            // (sums over the band's lpb lanes: lane exchanges inside a row, LDS permutes across rows)
+            if (lpb >= 2) e = dpp_add_f64<0xB1>(e), ek = dpp_add_f64<0xB1>(ek);
+            if (lpb >= 4) e = dpp_add_f64<0x4E>(e), ek = dpp_add_f64<0x4E>(ek);
+            if (lpb >= 8) e = dpp_add_f64<0x141>(e), ek = dpp_add_f64<0x141>(ek);
+            if (lpb >= 16) e = dpp_add_f64<0x140>(e), ek = dpp_add_f64<0x140>(ek);
+            if (lpb >= 32) e += __shfl_xor(e, 16, 64), ek += __shfl_xor(ek, 16, 64);
+            if (lpb >= 64) e += __shfl_xor(e, 32, 64), ek += __shfl_xor(ek, 32, 64);
             // the band's sums sit in its first lane; totals over the frame's bands
             const bool head = b < nseg && sl == 0;
             const T total = frame_sum<G>(head ? e : (T)0), num = frame_sum<G>(head ? ek : (T)0);
