@@ -290,7 +290,8 @@ def test_stereo_frames_at_the_first_and_last_bytes_of_the_buffer(oracle, wlen, i
                 _compare(g, ref, kw, f64)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MFCC_FUZZ_SEEDS", "48"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MFCC_FUZZ_FIRST", "0")),
+                                        int(os.environ.get("MFCC_FUZZ_FIRST", "0")) + int(os.environ.get("MFCC_FUZZ_SEEDS", "48"))))
 def test_random_configurations(oracle, seed, tuning):
     """Seeded random walk over the option space (frame geometry, channel layouts, feature flags,
     delta orders and windows, z-norm, batches of ragged utterances at odd byte offsets): whichever
