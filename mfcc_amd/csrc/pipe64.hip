@@ -631,8 +631,10 @@ __device__ __forceinline__ void pipew_expand(cpx<double> (&v)[16], int &zc, cons
     u64 nextNeg = 0, nextPos = 0; // sign of sample 2n of lane 0's pair r + 1 (the neighbour of lane 63's pair r), bit 63
 #pragma unroll
     for (int r = NZ - 1; r >= 0; --r) {
+        // (lane 0's predecessor, lane 63's second sample of the pair before: that register rotated by one
+        // lane is what the shift leaves in lane 0 -- two lane-exchange moves, no trip through a scalar)
         int carry = pred0;
-        if (r > 0) carry = __builtin_amdgcn_readlane(xb[r - 1], 63);
+        if (r > 0) carry = __builtin_amdgcn_mov_dpp(xb[r - 1], 0x13C, 0xf, 0xf, false);
         const double x0 = (double)wave_shr1i(xb[r], carry), x1 = (double)xa[r], x2 = (double)xb[r];
         double y1 = sub_mul_exact(x1, x0, preK);
         const double y2 = sub_mul_exact(x2, x1, preK);
