@@ -330,6 +330,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_pipe64(const FrontArgs<double> a
         {
             // instants 2n-1 (predecessor), 2n, 2n+1, 2n+2 start at byte (frame start + 2n) BPI
             const unsigned *src = raw + ((fr * a.inc) >> 1) + l;
+            // (one straight-line copy of the loop per setting of the zero-crossing option: a test inside it
+            // would cut it into NZ blocks, each waiting for its own two reads)
+            auto expand = [&](auto zcTag) {
+            constexpr bool ZCON = decltype(zcTag)::value;
 #pragma unroll
             for (int r = 0; r < NZ; ++r) {
                 unsigned d[DW];
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_pipe64(const FrontArgs<double> a
                 T y1 = sub_mul_exact(x[1], x[0], preK);
                 const T y2 = sub_mul_exact(x[2], x[1], preK);
                 if (r == 0 && firstTile && fr == 0 && l == 0) y1 = x[1] * ((T)1 - preK); // s[1] *= 1 - k
-                if (a.zcFlag) {
+                if constexpr (ZCON) {
                     const T y3 = sub_mul_exact(x[3], x[2], preK);
                     const int s0 = 2 * (l + G * r);
                     const bool c01 = (y1 < 0 && y2 > 0) || (y1 > 0 && y2 < 0);
@@ -354,6 +358,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_pipe64(const FrontArgs<double> a
                 const cpx<T> w = winT[lq + G * r];
                 v[r] = cpx<T>{y1 * w.x, y2 * w.y};
             }
+            };
+            if (a.zcFlag) expand(std::true_type{});
+            else expand(std::false_type{});
 #pragma unroll
             for (int r = NZ; r < PPL; ++r) v[r] = cpx<T>{0.0, 0.0};
         }
